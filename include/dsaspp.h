@@ -1,0 +1,369 @@
+/*
+ * dsaspp.h -- C ABI of libdsaspp.so, the MI355X (gfx950) kernels behind the DenseASPP
+ * forward/backward path.
+ *
+ * The reference implements this path with PyTorch built-ins called from Python
+ * (there is no FFI in the reference); each entry point below names the reference
+ * call site whose arithmetic it takes over.  All tensors are device pointers borrowed
+ * for the duration of the call; nothing is retained or freed.  Every call enqueues on
+ * the given HIP stream and returns without synchronising.  Return value: 0 on success,
+ * non-zero on error (message via dsaspp_last_error(), thread-local).  No C++ exception
+ * crosses this boundary.
+ *
+ * Layouts: activations are NHWC with an explicit pixel stride ("ld", in elements) so a
+ * layer can read or write a channel slice of a wider feature slab; bf16 unless stated.
+ * Convolution weights are bf16 [cout][taps][cin] (K contiguous).  Channel counts, channel
+ * offsets and strides must be multiples of 8 (16-byte chunks).
+ */
+#ifndef DSASPP_H
+#define DSASPP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dsaspp_stream_t; /* hipStream_t */
+
+#define DSASPP_STAT_REPLICAS 16 /* per-channel sums are spread over this many replica rows */
+
+int dsaspp_version(void);
+const char* dsaspp_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Fused [BN scale/shift -> ReLU -> (per-image channel mask)] -> convolution (1x1 or 3x3
+ * dilated, stride 1, 'same' zero padding applied AFTER the prologue) -> epilogue.
+ * Replaces nn.BatchNorm2d + nn.ReLU + nn.Conv2d of a dense layer / transition / ASPP
+ * branch and the torch.cat that follows (reference call sites graph_seg_main.py:237,
+ * graph_seg_test.py:144; cousin op models/bfp_net.py:60-62), and, with transposed
+ * weights, their data-gradient in loss.backward() (graph_seg_main.py:239).
+ *
+ * Epilogue, per output element v (fp32 accumulator), pixel m of image n, channel c:
+ *   v += bias[c]; v *= out_mask[n*out_mask_ld + c];
+ *   if (epi_relu) { pre = ref[m*ldref+c] * e_scale[c] + e_shift[c] (ref itself when
+ *                   e_scale is NULL); if (pre <= 0) v = 0; }
+ *   if (s_acc)   { s_acc[rep][c] += v;  s_acc[rep][cout+c] += v * (ref - e_mean[c]) * e_rstd[c]; }
+ *   if (g)       { t = v * (e_scale ? e_scale[c] : 1);  g[m*ldg+c] = (g_accumulate ? g + t : t); }
+ *   else         { y[m*ldy+c] = v (bf16, or fp32 when y_f32);
+ *                  if (stat_acc) { stat_acc[rep][c] += v_stored; stat_acc[rep][cout+c] += v_stored^2; } }
+ * where rep = blockIdx % DSASPP_STAT_REPLICAS and the stat buffers are fp32
+ * [DSASPP_STAT_REPLICAS][2*cout].
+ */
+typedef struct dsaspp_conv_desc {
+    int32_t n_img, H, W;      /* feature-map geometry (input == output) */
+    int32_t cin, cout;        /* GEMM K per tap, GEMM N */
+    int32_t taps, dil;        /* 1 (1x1) or 9 (3x3 with dilation dil) */
+    const void* x;            /* bf16 NHWC input, channel offset already applied */
+    int32_t ldx;
+    const void* w;            /* bf16 [cout][taps*cin] */
+    const float* in_scale;    /* [cin] or NULL (identity) */
+    const float* in_shift;    /* [cin] or NULL */
+    int32_t in_relu;
+    const float* in_mask;     /* [n_img][in_mask_ld] per-image channel multiplier or NULL */
+    int32_t in_mask_ld;
+    const float* bias;        /* [cout] or NULL */
+    const float* out_mask;    /* [n_img][out_mask_ld] or NULL */
+    int32_t out_mask_ld;
+    void* y;                  /* output (bf16, or fp32 if y_f32) ; unused when g != NULL */
+    int32_t ldy;
+    int32_t y_f32;
+    float* stat_acc;          /* [R][2*cout] sum / sum of squares of the stored output, or NULL */
+    int32_t epi_relu;         /* mask by sign of the reference pre-activation */
+    const void* ref;          /* bf16 [M][ldref] */
+    int32_t ldref;
+    const float* e_scale;     /* [cout] or NULL */
+    const float* e_shift;
+    const float* e_mean;
+    const float* e_rstd;
+    float* s_acc;             /* [R][2*cout] sum(v), sum(v*xhat) or NULL */
+    float* g;                 /* fp32 gradient slab [M][ldg] or NULL */
+    int32_t ldg;
+    int32_t g_accumulate;
+} dsaspp_conv_desc;
+
+int dsaspp_conv_fwd(const dsaspp_conv_desc* d, dsaspp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Weight gradient of the same convolution: dw[cout][taps][cin] (fp32) += sum over pixels
+ * of dz[m][cout] * A[m + tap offset][cin], with A = prologue(x) recomputed on the fly
+ * (never stored).  Replaces the weight-gradient half of loss.backward()
+ * (reference graph_seg_main.py:239).  dw must be zeroed by the caller before the first
+ * accumulation of a step; accumulation is by fp32 atomics (split over pixel ranges).
+ */
+typedef struct dsaspp_wgrad_desc {
+    int32_t n_img, H, W;
+    int32_t cin, cout;
+    int32_t taps, dil;
+    const void* x;            /* bf16 NHWC forward input */
+    int32_t ldx;
+    const float* in_scale;
+    const float* in_shift;
+    int32_t in_relu;
+    const float* in_mask;
+    int32_t in_mask_ld;
+    const void* dz;           /* bf16 [M][lddz] gradient w.r.t. the conv output */
+    int32_t lddz;
+    float* dw;                /* fp32 [cout][taps*cin] */
+    int32_t ksplit;           /* pixel-range splits (<=0: library picks) */
+} dsaspp_wgrad_desc;
+
+int dsaspp_conv_wgrad(const dsaspp_wgrad_desc* d, dsaspp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * BatchNorm bookkeeping (replaces the statistics side of nn.BatchNorm2d in train()/eval(),
+ * reference graph_seg_main.py:162,312; graph_seg_test.py:136).
+ *
+ * For channel c in [0,C):
+ *   if use_running:      mean = running_mean[c], var = running_var[c]
+ *   else if c in [acc_c0, acc_c0+acc_cn): mean/var from acc (replica sums of x and x^2 over
+ *                        `count` elements; acc is indexed by c-acc_c0 with width acc_cn and is
+ *                        zeroed afterwards), stored to mean[c]/var[c]/rstd[c]
+ *   else                 mean/var read from mean[c]/var[c]
+ *   scale[c] = gamma[c]*rsqrt(var+eps); shift[c] = beta[c]-mean*scale[c]
+ *   training (!use_running) and running_mean != NULL: running stats updated with `momentum`
+ *   (unbiased variance), *num_batches_tracked += 1.
+ */
+typedef struct dsaspp_bn_desc {
+    int32_t C;
+    float* acc;               /* [R][2*acc_cn] or NULL */
+    int32_t acc_c0, acc_cn;
+    float count;              /* elements per channel (N*H*W) */
+    float* mean;              /* [C] slab-level batch statistics (in/out) */
+    float* var;
+    float* rstd;
+    const float* gamma;       /* [C] or NULL (identity affine) */
+    const float* beta;
+    float* running_mean;      /* [C] or NULL */
+    float* running_var;
+    int64_t* num_batches_tracked;
+    float momentum, eps;
+    int32_t use_running;
+    float* scale;             /* [C] out (may be NULL) */
+    float* shift;
+} dsaspp_bn_desc;
+
+int dsaspp_bn_finalize(const dsaspp_bn_desc* d, dsaspp_stream_t stream);
+
+/* BatchNorm backward bookkeeping (training mode).  acc holds replica sums S1 = sum(dy),
+ * S2 = sum(dy*xhat) for C channels and is zeroed afterwards.
+ *   dbeta[c] += S1, dgamma[c] += S2   (when non-NULL)
+ *   mode 0 (private input): coefficient tables for dsaspp_bn_bwd_apply:
+ *        A = scale, B = -scale*rstd*S2/count, Cc = -scale*S1/count - B*mean
+ *   mode 1 (input is a shared feature slab): corr1[c] += scale*S1/count, corr2[c] += scale*S2/count
+ */
+typedef struct dsaspp_bn_bwd_desc {
+    int32_t C;
+    float* acc;               /* [R][2*C] */
+    float count;
+    const float* scale;       /* forward scale (gamma*rstd) */
+    const float* mean;
+    const float* rstd;
+    float* dgamma;
+    float* dbeta;
+    int32_t mode;
+    float* coefA;
+    float* coefB;
+    float* coefC;
+    float* corr1;
+    float* corr2;
+} dsaspp_bn_bwd_desc;
+
+int dsaspp_bn_bwd_finalize(const dsaspp_bn_bwd_desc* d, dsaspp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Row-wise (pixel x channel) streaming kernels, NHWC, 8 channels per lane.
+ */
+
+/* y = relu?(x*scale+shift) -> bf16, optional statistics of the stored values
+ * (features.norm5 + the in-place ReLU heading ASPP_3). */
+typedef struct dsaspp_bnact_desc {
+    int64_t M; int32_t C;
+    const void* x; int32_t ldx;
+    const float* scale; const float* shift; int32_t relu;
+    void* y; int32_t ldy;
+    float* stat_acc;          /* [R][2*C] or NULL */
+} dsaspp_bnact_desc;
+int dsaspp_bn_act(const dsaspp_bnact_desc* d, dsaspp_stream_t stream);
+
+/* Gradient read-out from a slab:
+ *   v = g[m][c] - corr1[c] - ((xs[m][c]-s_mean[c])*s_rstd[c])*corr2[c]   (corr terms when corr1 != NULL)
+ *   v *= mask[n][c]                                                       (when mask != NULL)
+ *   if relu: pre = yref*r_scale+r_shift (yref itself if r_scale NULL); if pre<=0: v = 0
+ *   dz[m][c] = bf16(v);  s_acc += {v, v*((yref-r_mean)*r_rstd)} (when s_acc != NULL)
+ *   colsum[c] += v (when non-NULL; plain fp32 atomics) */
+typedef struct dsaspp_gradx_desc {
+    int64_t M; int32_t C; int32_t hw;       /* hw = pixels per image (for mask row lookup) */
+    const float* g; int32_t ldg;
+    const float* corr1; const float* corr2;
+    const void* xs; int32_t ldxs; const float* s_mean; const float* s_rstd;
+    const float* mask; int32_t mask_ld;
+    int32_t relu;
+    const void* yref; int32_t ldyref;
+    const float* r_scale; const float* r_shift; const float* r_mean; const float* r_rstd;
+    void* dz; int32_t lddz;
+    float* s_acc;
+    float* colsum;
+} dsaspp_gradx_desc;
+int dsaspp_grad_extract(const dsaspp_gradx_desc* d, dsaspp_stream_t stream);
+
+/* dy = A[c]*dr + B[c]*y + Cc[c] -> bf16 ; colsum[c] += dy when non-NULL */
+typedef struct dsaspp_bnapply_desc {
+    int64_t M; int32_t C;
+    const void* dr; int32_t lddr;
+    const void* y; int32_t ldy;
+    const float* coefA; const float* coefB; const float* coefC;
+    void* dy; int32_t lddy;
+    float* colsum;
+} dsaspp_bnapply_desc;
+int dsaspp_bn_bwd_apply(const dsaspp_bnapply_desc* d, dsaspp_stream_t stream);
+
+/* 2x2 average pooling (transition1) forward (+ statistics) and backward. */
+typedef struct dsaspp_pool_desc {
+    int32_t n_img, H, W, C;   /* input geometry (H, W even) */
+    const void* x; int32_t ldx;
+    void* y; int32_t ldy;     /* output geometry H/2 x W/2 */
+    float* stat_acc;
+} dsaspp_pool_desc;
+int dsaspp_avgpool2_fwd(const dsaspp_pool_desc* d, dsaspp_stream_t stream);
+/* dx[n][h][w][c] = dy[n][h/2][w/2][c] / 4 ; here x is the gradient OUTPUT (full size), y the INPUT */
+int dsaspp_avgpool2_bwd(const dsaspp_pool_desc* d, dsaspp_stream_t stream);
+
+/* Stem: 7x7/2 im2col of the NCHW fp32 network input to bf16 rows [N*Ho*Wo][ldcol]
+ * (K order (ky,kx,ci), zero padded), so conv0 runs as a 1x1 GEMM; and the
+ * BN+ReLU -> 3x3/2 max pooling that follows, with its backward. */
+typedef struct dsaspp_im2col_desc {
+    int32_t n_img, H, W;      /* input image size; output Ho = H/2, Wo = W/2 */
+    const float* x;           /* NCHW fp32, 3 channels */
+    void* col; int32_t ldcol; /* >= 152 and multiple of 8; columns >= 147 zero filled */
+} dsaspp_im2col_desc;
+int dsaspp_stem_im2col(const dsaspp_im2col_desc* d, dsaspp_stream_t stream);
+
+typedef struct dsaspp_maxpool_desc {
+    int32_t n_img, H, W, C;   /* input (conv0 output) geometry; output ceil(H/2) x ceil(W/2), H, W even */
+    const void* x; int32_t ldx;       /* raw conv0 output bf16 */
+    const float* scale; const float* shift; /* norm0 */
+    void* y; int32_t ldy;             /* pooled relu(bn(x)) bf16 */
+    uint8_t* argmax;                  /* [N*Ho*Wo][C] window position 0..8, or NULL */
+    float* stat_acc;
+    /* backward only */
+    const void* dy; int32_t lddy;     /* bf16 gradient w.r.t. pooled output */
+    void* dr; int32_t lddr;           /* bf16 masked gradient w.r.t. norm0 output */
+    const float* mean; const float* rstd;
+    float* s_acc;
+} dsaspp_maxpool_desc;
+int dsaspp_maxpool3s2_fwd(const dsaspp_maxpool_desc* d, dsaspp_stream_t stream);
+int dsaspp_maxpool3s2_bwd(const dsaspp_maxpool_desc* d, dsaspp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Bilinear x8 upsample (align_corners=False) fused with softmax cross-entropy
+ * (replaces nn.Upsample(scale_factor=8, mode='bilinear') + CrossEntropyLoss(ignore_index)
+ * + their backward; reference graph_seg_main.py:216,238-239).
+ *   logits: fp32 NHWC [N][h][w][ldl] low-resolution class scores (n_class <= 32 used)
+ *   labels: int64 [N][8h][8w]
+ *   dlogits: fp32 same shape as logits; must be zero on entry, receives the UNNORMALISED
+ *            gradient (sum over pixels of softmax - onehot)
+ *   accum:  fp32[2] zero on entry: {sum of per-pixel losses, number of non-ignored pixels}
+ * dsaspp_ce_finalize then divides: loss[0] = accum[0]/accum[1], dlogits /= accum[1]
+ * (times grad_scale), writes a bf16 copy for the classifier backward and the per-class
+ * column sums (the classifier bias gradient, += into dbias when non-NULL).
+ */
+typedef struct dsaspp_ce_desc {
+    int32_t n_img, h, w;      /* low-res geometry */
+    int32_t n_class; int32_t ldl;
+    const float* logits;
+    const int64_t* labels;
+    int32_t ignore_index;
+    float* dlogits;
+    float* accum;
+    /* finalize */
+    float grad_scale;
+    float* loss;
+    void* dlogits_bf16; int32_t lddb;
+    float* dbias;
+} dsaspp_ce_desc;
+int dsaspp_upsample8_ce(const dsaspp_ce_desc* d, dsaspp_stream_t stream);
+int dsaspp_ce_finalize(const dsaspp_ce_desc* d, dsaspp_stream_t stream);
+
+/* Materialised x8 upsample for the plain forward() API: fp32 NHWC low-res -> fp32 NCHW
+ * [N][n_class][8h][8w]; its adjoint; and the inference variant that writes only the arg-max
+ * class per pixel (replaces Upsample + F.softmax + argmax, reference graph_seg_test.py:144-146,62). */
+typedef struct dsaspp_up_desc {
+    int32_t n_img, h, w, n_class, ldl;
+    const float* logits;      /* low-res NHWC fp32 (fwd/argmax: input ; bwd: OUTPUT, zero on entry) */
+    float* out;               /* NCHW fp32 full-res (fwd: output ; bwd: input gradient) */
+    int64_t* argmax;          /* [N][8h][8w] */
+} dsaspp_up_desc;
+int dsaspp_upsample8_fwd(const dsaspp_up_desc* d, dsaspp_stream_t stream);
+int dsaspp_upsample8_bwd(const dsaspp_up_desc* d, dsaspp_stream_t stream);
+int dsaspp_upsample8_argmax(const dsaspp_up_desc* d, dsaspp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Parameter-side kernels over the flat parameter arena (adjacent to the path:
+ * torch.optim.Adam(weight_decay) + poly learning rate, reference graph_seg_main.py:186,241-245).
+ */
+/* p, g, m, v fp32[n]; Adam with coupled L2 (g += wd*p), bias correction from `step`
+ * (1-based); also refreshes the bf16 shadow copy w16[n]. */
+typedef struct dsaspp_adam_desc {
+    int64_t n;
+    float* p; const float* g; float* m; float* v;
+    void* w16;
+    float lr, beta1, beta2, eps, weight_decay;
+    int32_t step;
+    float grad_scale;         /* multiply g first (e.g. 1/world_size) */
+} dsaspp_adam_desc;
+int dsaspp_adam_step(const dsaspp_adam_desc* d, dsaspp_stream_t stream);
+
+/* fp32 -> bf16 cast of the flat arena */
+int dsaspp_cast_bf16(const float* src, void* dst, int64_t n, dsaspp_stream_t stream);
+
+/* Transposed weight copies for the data-gradient kernels, batched:
+ * dst[c][taps-1-t][n] = src[n][t][c] for each table entry. */
+typedef struct dsaspp_wt_entry {
+    int64_t src_off, dst_off; /* element offsets into src / dst arenas (bf16) */
+    int32_t cout, cin, taps, pad;
+} dsaspp_wt_entry;
+int dsaspp_weight_transpose(const void* src, void* dst, const dsaspp_wt_entry* table_dev,
+                            int32_t n_entries, int64_t max_elems, dsaspp_stream_t stream);
+
+/* fp32 2-D strided copy (row pad / unpad of the stem weight and its gradient);
+ * dst[r][c] = src[r][c] (+= when accumulate) for c < cols; dst columns [cols, dst_cols) are zeroed. */
+int dsaspp_copy2d_f32(const float* src, int32_t lds, float* dst, int32_t ldd,
+                      int32_t rows, int32_t cols, int32_t dst_cols, int32_t accumulate,
+                      dsaspp_stream_t stream);
+/* same, fp32 source rows -> bf16 destination rows */
+int dsaspp_copy2d_f32_bf16(const float* src, int32_t lds, void* dst, int32_t ldd,
+                           int32_t rows, int32_t cols, int32_t dst_cols, dsaspp_stream_t stream);
+
+int dsaspp_memset_async(void* p, int32_t value, int64_t bytes, dsaspp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Programs: a recorded sequence of the calls above, replayed with one host call
+ * (and optionally as one captured HIP graph).  Descriptors are copied at record time.
+ */
+typedef struct dsaspp_program dsaspp_program;
+enum {
+    DSASPP_OP_CONV = 1, DSASPP_OP_WGRAD, DSASPP_OP_BN_FINALIZE, DSASPP_OP_BN_BWD_FINALIZE,
+    DSASPP_OP_BN_ACT, DSASPP_OP_GRAD_EXTRACT, DSASPP_OP_BN_BWD_APPLY, DSASPP_OP_AVGPOOL_FWD,
+    DSASPP_OP_AVGPOOL_BWD, DSASPP_OP_IM2COL, DSASPP_OP_MAXPOOL_FWD, DSASPP_OP_MAXPOOL_BWD,
+    DSASPP_OP_UPCE, DSASPP_OP_CE_FINALIZE, DSASPP_OP_UP_FWD, DSASPP_OP_UP_BWD, DSASPP_OP_UP_ARGMAX,
+    DSASPP_OP_MEMSET, DSASPP_OP_COPY2D, DSASPP_OP_COPY2D_BF16
+};
+dsaspp_program* dsaspp_program_create(void);
+void dsaspp_program_destroy(dsaspp_program* p);
+/* desc points at the descriptor struct of that op; for MEMSET / COPY2D see dsaspp_generic_desc */
+typedef struct dsaspp_generic_desc {
+    const void* src; void* dst;
+    int64_t n;                /* bytes (memset) */
+    int32_t value;
+    int32_t lds, ldd, rows, cols, dst_cols, accumulate;
+} dsaspp_generic_desc;
+int dsaspp_program_add(dsaspp_program* p, int32_t op, const void* desc, int64_t desc_bytes);
+int dsaspp_program_size(const dsaspp_program* p);
+/* run ops [first, last) ; last < 0 means to the end */
+int dsaspp_program_run(dsaspp_program* p, int32_t first, int32_t last, dsaspp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSASPP_H */

@@ -1,0 +1,92 @@
+"""The product backend: descriptors -> dsaspp_program inside libdsaspp.so (HIP, gfx950)."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class HipProgram:
+    def __init__(self, lib, handle, keepalive):
+        self.lib, self.handle, self.keepalive = lib, handle, keepalive
+
+    def run(self, stream=None, first=0, last=-1):
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.lib.dsaspp_program_run(self.handle, first, last, ctypes.c_void_p(stream)))
+
+    def __len__(self):
+        return self.lib.dsaspp_program_size(self.handle)
+
+    def __del__(self):
+        try:
+            self.lib.dsaspp_program_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def fill_desc(struct, fields):
+    d = struct()
+    known = {n for n, _ in struct._fields_}
+    for k, v in fields.items():
+        if k not in known:
+            raise KeyError('%s has no field %r' % (struct.__name__, k))
+        if v is None:
+            continue
+        if hasattr(v, 'ptr'):
+            v = v.ptr()
+        setattr(d, k, v)
+    return d
+
+
+class HipBackend:
+    """Runs descriptor lists through libdsaspp.so.  There is no other compute backend in the package."""
+    stat_replicas = _lib.STAT_REPLICAS
+    act_dtype = torch.bfloat16
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    def compile(self, oplist):
+        h = self.lib.dsaspp_program_create()
+        if not h:
+            raise _lib.DsasppError('dsaspp_program_create failed')
+        prog = HipProgram(self.lib, h, oplist)
+        for kind, fields in oplist:
+            code, struct, _ = _lib.OPS[kind]
+            d = fill_desc(struct, fields)
+            _lib.check(self.lib.dsaspp_program_add(h, code, ctypes.byref(d), ctypes.sizeof(d)))
+        return prog
+
+    def call(self, kind, stream=None, **fields):
+        """Launch one kernel directly (op-level tests)."""
+        code, struct, entry = _lib.OPS[kind]
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        d = fill_desc(struct, fields)
+        _lib.check(getattr(self.lib, entry)(ctypes.byref(d), ctypes.c_void_p(stream)))
+
+    # ------------------------------------------------------------------ weight shadows
+    def refresh_weights(self, model):
+        """fp32 arena -> bf16 shadow (same offsets), padded stem rows, transposed copies for the dgrad convs."""
+        from . import spec as S
+        lib = self.lib
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        ar = model.arena
+        _lib.check(lib.dsaspp_cast_bf16(model._flat.data_ptr(), model._w16.data_ptr(), ar.size, stream))
+        e0 = ar.by_name['features.conv0.weight']
+        _lib.check(lib.dsaspp_copy2d_f32_bf16(model._flat.data_ptr() + 4 * e0.off, S.STEM_K, model._w0_16.data_ptr(),
+                                              S.STEM_KPAD, e0.rows, S.STEM_K, S.STEM_KPAD, stream))
+        if model._wt_table is None:
+            ents = [e for e in ar.entries if e.kind == 'conv']
+            tab = (_lib.wt_entry * len(ents))()
+            mx = 0
+            for i, e in enumerate(ents):
+                tab[i].src_off, tab[i].dst_off = e.off, e.toff
+                tab[i].cout, tab[i].cin, tab[i].taps = e.rows, e.cin, e.taps
+                mx = max(mx, e.numel)
+            raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).clone()
+            model._wt_table = (raw.to(model._flat.device), len(ents), mx)
+        tab_dev, n, mx = model._wt_table
+        _lib.check(lib.dsaspp_weight_transpose(model._w16.data_ptr(), model._wt16.data_ptr(), tab_dev.data_ptr(), n, mx,
+                                               stream))

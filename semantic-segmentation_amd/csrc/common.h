@@ -1,0 +1,85 @@
+// Shared device helpers for the gfx950 kernels of libdsaspp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dsaspp.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short u16;
+
+#define DS_R DSASPP_STAT_REPLICAS
+
+int dsaspp_set_error(const char* fmt, ...);
+
+#define DS_REQUIRE(cond, ...)                                  \
+    do {                                                       \
+        if (!(cond)) return dsaspp_set_error(__VA_ARGS__);     \
+    } while (0)
+
+#define DS_LAUNCH_CHECK(name)                                                          \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess) return dsaspp_set_error("%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ uint32_t f2bf_bits(float f) {
+    __bf16 b = (__bf16)f;  // round-to-nearest-even, NaN preserving (v_cvt_pk_bf16_f32)
+    return (uint32_t)__builtin_bit_cast(u16, b);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return f2bf_bits(lo) | (f2bf_bits(hi) << 16); }
+__device__ __forceinline__ float bf_round(float f) { return __uint_as_float(f2bf_bits(f) << 16); }
+
+// 8 bf16 (one 16-byte chunk) <-> 8 floats
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+    f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
+    f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    uint4 v;
+    v.x = pack_bf2(f[0], f[1]); v.y = pack_bf2(f[2], f[3]);
+    v.z = pack_bf2(f[4], f[5]); v.w = pack_bf2(f[6], f[7]);
+    return v;
+}
+__device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+__device__ __forceinline__ void store8f(float* p, const float (&f)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+}
+
+// Bijective XCD-aware block remap: blocks b and b+8 share an XCD (and its L2), so give each
+// XCD group a contiguous range of logical tile ids.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// Row-wise streaming kernels: a block is CGB channel groups (8 channels each) wide and
+// 256/CGB rows tall.  Reduce per-thread column partials over the rows of the block and add
+// them to a replica row of an accumulator [R][NS*C] (sum s of channel c at [rep][s*C + c]).
+template <int CGB, int NS>
+__device__ __forceinline__ void block_colsum(float (&part)[NS][8], float* lds /* 256*NS*8 floats */,
+                                             float* acc, int C, int cg0, int rep_stride, int rep) {
+    constexpr int RB = 256 / CGB;
+    const int cx = threadIdx.x % CGB, ry = threadIdx.x / CGB;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lds[(ry * CGB + cx) * (NS * 8) + s * 8 + e] = part[s][e];
+    __syncthreads();
+    for (int o = threadIdx.x; o < CGB * NS * 8; o += 256) {
+        const int ocx = o / (NS * 8), rest = o % (NS * 8);
+        const int s = rest / 8, e = rest % 8;
+        float t = 0.f;
+        for (int r = 0; r < RB; ++r) t += lds[(r * CGB + ocx) * (NS * 8) + rest];
+        const int c = (cg0 + ocx) * 8 + e;
+        if (c < C) atomicAdd(acc + (size_t)rep * rep_stride + s * C + c, t);
+    }
+}

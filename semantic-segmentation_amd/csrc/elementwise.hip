@@ -1,0 +1,543 @@
+// HBM-bound row-wise kernels around the convolutions: BatchNorm bookkeeping, slab gradient
+// read-out, BN backward application, pooling and the stem im2col.  NHWC bf16, one 16-byte
+// chunk (8 channels) per lane per row; per-channel sums are reduced in registers, then across
+// the block through LDS, then added to one of DS_R replica rows with fp32 atomics.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- BN finalize (forward)
+__global__ void bn_finalize_kernel(const dsaspp_bn_desc d) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && !d.use_running && d.num_batches_tracked) *d.num_batches_tracked += 1;
+    if (c >= d.C) return;
+    float mean, var;
+    if (d.use_running) {
+        mean = d.running_mean[c];
+        var = d.running_var[c];
+    } else {
+        const int a = c - d.acc_c0;
+        if (d.acc && a >= 0 && a < d.acc_cn) {
+            float s = 0.f, q = 0.f;
+            for (int r = 0; r < DS_R; ++r) {
+                float* row = d.acc + (size_t)r * 2 * d.acc_cn;
+                s += row[a];
+                q += row[d.acc_cn + a];
+                row[a] = 0.f;
+                row[d.acc_cn + a] = 0.f;
+            }
+            mean = s / d.count;
+            var = fmaxf(q / d.count - mean * mean, 0.f);
+            d.mean[c] = mean;
+            d.var[c] = var;
+            d.rstd[c] = rsqrtf(var + d.eps);
+        } else {
+            mean = d.mean[c];
+            var = d.var[c];
+        }
+        if (d.running_mean) {
+            const float unbiased = d.count > 1.f ? var * d.count / (d.count - 1.f) : var;
+            d.running_mean[c] = (1.f - d.momentum) * d.running_mean[c] + d.momentum * mean;
+            d.running_var[c] = (1.f - d.momentum) * d.running_var[c] + d.momentum * unbiased;
+        }
+    }
+    if (d.scale) {
+        const float rstd = rsqrtf(var + d.eps);
+        const float g = d.gamma ? d.gamma[c] : 1.f, b = d.beta ? d.beta[c] : 0.f;
+        const float sc = g * rstd;
+        d.scale[c] = sc;
+        d.shift[c] = b - mean * sc;
+    }
+}
+
+// ---------------------------------------------------------------- BN finalize (backward)
+__global__ void bn_bwd_finalize_kernel(const dsaspp_bn_bwd_desc d) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < DS_R; ++r) {
+        float* row = d.acc + (size_t)r * 2 * d.C;
+        s1 += row[c];
+        s2 += row[d.C + c];
+        row[c] = 0.f;
+        row[d.C + c] = 0.f;
+    }
+    if (d.dbeta) d.dbeta[c] += s1;
+    if (d.dgamma) d.dgamma[c] += s2;
+    const float sc = d.scale[c];
+    const float inv = 1.f / d.count;
+    if (d.mode == 0) {
+        const float B = -sc * d.rstd[c] * s2 * inv;
+        d.coefA[c] = sc;
+        d.coefB[c] = B;
+        d.coefC[c] = -sc * s1 * inv - B * d.mean[c];
+    } else {
+        d.corr1[c] += sc * s1 * inv;
+        d.corr2[c] += sc * s2 * inv;
+    }
+}
+
+// ---------------------------------------------------------------- y = relu(x*scale+shift) (+stats)
+template <int CGB>
+__global__ __launch_bounds__(256) void bn_act_kernel(const dsaspp_bnact_desc d) {
+    __shared__ float red[256 * 16];
+    constexpr int RB = 256 / CGB;
+    const int cx = threadIdx.x % CGB, ry = threadIdx.x / CGB;
+    const int cg = blockIdx.x * CGB + cx;
+    const int c = cg * 8;
+    const bool act = c < d.C;
+    float sc[8], sh[8], part[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; part[0][e] = 0.f; part[1][e] = 0.f; }
+    if (act && d.scale) { load8f(d.scale + c, sc); load8f(d.shift + c, sh); }
+    const u16* xg = reinterpret_cast<const u16*>(d.x);
+    u16* yg = reinterpret_cast<u16*>(d.y);
+    if (act) {
+        for (int64_t m = (int64_t)blockIdx.y * RB + ry; m < d.M; m += (int64_t)gridDim.y * RB) {
+            const uint4 v = *reinterpret_cast<const uint4*>(xg + m * d.ldx + c);
+            float f[8];
+            unpack8(v, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                f[e] = fmaf(f[e], sc[e], sh[e]);
+                if (d.relu) f[e] = fmaxf(f[e], 0.f);
+            }
+            const uint4 o = pack8(f);
+            *reinterpret_cast<uint4*>(yg + m * d.ldy + c) = o;
+            if (d.stat_acc) {
+                float g[8];
+                unpack8(o, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { part[0][e] += g[e]; part[1][e] += g[e] * g[e]; }
+            }
+        }
+    }
+    if (d.stat_acc) block_colsum<CGB, 2>(part, red, d.stat_acc, d.C, blockIdx.x * CGB, 2 * d.C, blockIdx.y % DS_R);
+}
+
+// ---------------------------------------------------------------- slab gradient read-out
+template <int CGB>
+__global__ __launch_bounds__(256) void grad_extract_kernel(const dsaspp_gradx_desc d) {
+    __shared__ float red[256 * 16];
+    constexpr int RB = 256 / CGB;
+    const int cx = threadIdx.x % CGB, ry = threadIdx.x / CGB;
+    const int cg = blockIdx.x * CGB + cx;
+    const int c = cg * 8;
+    const bool act = c < d.C;
+    float k1[8], k2[8], sm[8], sr[8], rs[8], rh[8], rm[8], rr[8], part[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        k1[e] = 0.f; k2[e] = 0.f; sm[e] = 0.f; sr[e] = 1.f; rs[e] = 1.f; rh[e] = 0.f; rm[e] = 0.f; rr[e] = 1.f;
+        part[0][e] = 0.f; part[1][e] = 0.f;
+    }
+    if (act) {
+        if (d.corr1) { load8f(d.corr1 + c, k1); load8f(d.corr2 + c, k2); load8f(d.s_mean + c, sm); load8f(d.s_rstd + c, sr); }
+        if (d.r_scale) { load8f(d.r_scale + c, rs); load8f(d.r_shift + c, rh); }
+        if (d.s_acc) { load8f(d.r_mean + c, rm); load8f(d.r_rstd + c, rr); }
+    }
+    const u16* xs = reinterpret_cast<const u16*>(d.xs);
+    const u16* yr = reinterpret_cast<const u16*>(d.yref);
+    u16* dz = reinterpret_cast<u16*>(d.dz);
+    if (act) {
+        for (int64_t m = (int64_t)blockIdx.y * RB + ry; m < d.M; m += (int64_t)gridDim.y * RB) {
+            float v[8];
+            load8f(d.g + m * d.ldg + c, v);
+            if (d.corr1) {
+                float x[8];
+                unpack8(*reinterpret_cast<const uint4*>(xs + m * d.ldxs + c), x);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] -= k1[e] + ((x[e] - sm[e]) * sr[e]) * k2[e];
+            }
+            if (d.mask) {
+                float mk[8];
+                load8f(d.mask + (m / d.hw) * d.mask_ld + c, mk);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= mk[e];
+            }
+            float y[8];
+            if (d.relu || d.s_acc) unpack8(*reinterpret_cast<const uint4*>(yr + m * d.ldyref + c), y);
+            if (d.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pre = d.r_scale ? fmaf(y[e], rs[e], rh[e]) : y[e];
+                    if (!(pre > 0.f)) v[e] = 0.f;
+                }
+            }
+            *reinterpret_cast<uint4*>(dz + m * d.lddz + c) = pack8(v);
+            if (d.s_acc) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { part[0][e] += v[e]; part[1][e] += v[e] * ((y[e] - rm[e]) * rr[e]); }
+            } else if (d.colsum) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part[0][e] += v[e];
+            }
+        }
+    }
+    if (d.s_acc) block_colsum<CGB, 2>(part, red, d.s_acc, d.C, blockIdx.x * CGB, 2 * d.C, blockIdx.y % DS_R);
+    else if (d.colsum) {
+        float p1[1][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p1[0][e] = part[0][e];
+        block_colsum<CGB, 1>(p1, red, d.colsum, d.C, blockIdx.x * CGB, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------- dy = A*dr + B*y + C
+template <int CGB>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const dsaspp_bnapply_desc d) {
+    __shared__ float red[256 * 8];
+    constexpr int RB = 256 / CGB;
+    const int cx = threadIdx.x % CGB, ry = threadIdx.x / CGB;
+    const int cg = blockIdx.x * CGB + cx;
+    const int c = cg * 8;
+    const bool act = c < d.C;
+    float A[8], B[8], Cc[8], part[1][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { A[e] = 0.f; B[e] = 0.f; Cc[e] = 0.f; part[0][e] = 0.f; }
+    if (act) { load8f(d.coefA + c, A); load8f(d.coefB + c, B); load8f(d.coefC + c, Cc); }
+    const u16* dr = reinterpret_cast<const u16*>(d.dr);
+    const u16* yy = reinterpret_cast<const u16*>(d.y);
+    u16* dy = reinterpret_cast<u16*>(d.dy);
+    if (act) {
+        for (int64_t m = (int64_t)blockIdx.y * RB + ry; m < d.M; m += (int64_t)gridDim.y * RB) {
+            float a[8], y[8], o[8];
+            unpack8(*reinterpret_cast<const uint4*>(dr + m * d.lddr + c), a);
+            unpack8(*reinterpret_cast<const uint4*>(yy + m * d.ldy + c), y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o[e] = fmaf(A[e], a[e], fmaf(B[e], y[e], Cc[e])); part[0][e] += o[e]; }
+            *reinterpret_cast<uint4*>(dy + m * d.lddy + c) = pack8(o);
+        }
+    }
+    if (d.colsum) block_colsum<CGB, 1>(part, red, d.colsum, d.C, blockIdx.x * CGB, 0, 0);
+}
+
+// ---------------------------------------------------------------- 2x2 average pooling
+template <int CGB>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const dsaspp_pool_desc d) {
+    __shared__ float red[256 * 16];
+    constexpr int RB = 256 / CGB;
+    const int cx = threadIdx.x % CGB, ry = threadIdx.x / CGB;
+    const int c = (blockIdx.x * CGB + cx) * 8;
+    const bool act = c < d.C;
+    const int Ho = d.H / 2, Wo = d.W / 2;
+    const int64_t Mo = (int64_t)d.n_img * Ho * Wo;
+    float part[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { part[0][e] = 0.f; part[1][e] = 0.f; }
+    const u16* xg = reinterpret_cast<const u16*>(d.x);
+    u16* yg = reinterpret_cast<u16*>(d.y);
+    if (act) {
+        for (int64_t m = (int64_t)blockIdx.y * RB + ry; m < Mo; m += (int64_t)gridDim.y * RB) {
+            const int n = (int)(m / (Ho * Wo));
+            const int rem = (int)(m - (int64_t)n * Ho * Wo);
+            const int ho = rem / Wo, wo = rem - ho * Wo;
+            const int64_t p00 = ((int64_t)n * d.H + 2 * ho) * d.W + 2 * wo;
+            float a[8], b[8], e0[8], e1[8], o[8];
+            unpack8(*reinterpret_cast<const uint4*>(xg + p00 * d.ldx + c), a);
+            unpack8(*reinterpret_cast<const uint4*>(xg + (p00 + 1) * d.ldx + c), b);
+            unpack8(*reinterpret_cast<const uint4*>(xg + (p00 + d.W) * d.ldx + c), e0);
+            unpack8(*reinterpret_cast<const uint4*>(xg + (p00 + d.W + 1) * d.ldx + c), e1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = 0.25f * ((a[e] + b[e]) + (e0[e] + e1[e]));
+            const uint4 ov = pack8(o);
+            *reinterpret_cast<uint4*>(yg + m * d.ldy + c) = ov;
+            if (d.stat_acc) {
+                float g[8];
+                unpack8(ov, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { part[0][e] += g[e]; part[1][e] += g[e] * g[e]; }
+            }
+        }
+    }
+    if (d.stat_acc) block_colsum<CGB, 2>(part, red, d.stat_acc, d.C, blockIdx.x * CGB, 2 * d.C, blockIdx.y % DS_R);
+}
+
+// dx (full size, d.x) <- dy (half size, d.y) / 4
+template <int CGB>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const dsaspp_pool_desc d) {
+    constexpr int RB = 256 / CGB;
+    const int cx = threadIdx.x % CGB, ry = threadIdx.x / CGB;
+    const int c = (blockIdx.x * CGB + cx) * 8;
+    if (c >= d.C) return;
+    const int Ho = d.H / 2, Wo = d.W / 2;
+    const int64_t Mi = (int64_t)d.n_img * d.H * d.W;
+    u16* xg = reinterpret_cast<u16*>(const_cast<void*>(d.x));
+    const u16* yg = reinterpret_cast<const u16*>(d.y);
+    for (int64_t m = (int64_t)blockIdx.y * RB + ry; m < Mi; m += (int64_t)gridDim.y * RB) {
+        const int n = (int)(m / (d.H * d.W));
+        const int rem = (int)(m - (int64_t)n * d.H * d.W);
+        const int h = rem / d.W, w = rem - h * d.W;
+        const int64_t po = ((int64_t)n * Ho + (h >> 1)) * Wo + (w >> 1);
+        float a[8];
+        unpack8(*reinterpret_cast<const uint4*>(yg + po * d.ldy + c), a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] *= 0.25f;
+        *reinterpret_cast<uint4*>(xg + m * d.ldx + c) = pack8(a);
+    }
+}
+
+// ---------------------------------------------------------------- stem im2col (7x7, stride 2, pad 3)
+// One thread per (output pixel, 8-column chunk).  Column k = (ky*7+kx)*3 + ci.
+__global__ __launch_bounds__(256) void im2col_kernel(const dsaspp_im2col_desc d) {
+    const int Ho = d.H / 2, Wo = d.W / 2;
+    const int nchunk = d.ldcol / 8;
+    const int64_t total = (int64_t)d.n_img * Ho * Wo * nchunk;
+    const int64_t plane = (int64_t)d.H * d.W;
+    u16* col = reinterpret_cast<u16*>(d.col);
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(idx % nchunk);
+        const int64_t m = idx / nchunk;
+        const int n = (int)(m / (Ho * Wo));
+        const int rem = (int)(m - (int64_t)n * Ho * Wo);
+        const int ho = rem / Wo, wo = rem - ho * Wo;
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ch * 8 + e;
+            float v = 0.f;
+            if (k < 147) {
+                const int t = k / 3, ci = k - t * 3;
+                const int ky = t / 7, kx = t - ky * 7;
+                const int hi = 2 * ho - 3 + ky, wi = 2 * wo - 3 + kx;
+                if ((unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W)
+                    v = d.x[((int64_t)n * 3 + ci) * plane + (int64_t)hi * d.W + wi];
+            }
+            f[e] = v;
+        }
+        *reinterpret_cast<uint4*>(col + m * d.ldcol + ch * 8) = pack8(f);
+    }
+}
+
+// ---------------------------------------------------------------- BN+ReLU -> maxpool 3x3 stride 2 pad 1
+template <int CGB>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const dsaspp_maxpool_desc d) {
+    __shared__ float red[256 * 16];
+    constexpr int RB = 256 / CGB;
+    const int cx = threadIdx.x % CGB, ry = threadIdx.x / CGB;
+    const int c = (blockIdx.x * CGB + cx) * 8;
+    const bool act = c < d.C;
+    const int Ho = d.H / 2, Wo = d.W / 2;
+    const int64_t Mo = (int64_t)d.n_img * Ho * Wo;
+    float sc[8], sh[8], part[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; part[0][e] = 0.f; part[1][e] = 0.f; }
+    if (act) { load8f(d.scale + c, sc); load8f(d.shift + c, sh); }
+    const u16* xg = reinterpret_cast<const u16*>(d.x);
+    u16* yg = reinterpret_cast<u16*>(d.y);
+    if (act) {
+        for (int64_t m = (int64_t)blockIdx.y * RB + ry; m < Mo; m += (int64_t)gridDim.y * RB) {
+            const int n = (int)(m / (Ho * Wo));
+            const int rem = (int)(m - (int64_t)n * Ho * Wo);
+            const int ho = rem / Wo, wo = rem - ho * Wo;
+            float best[8];
+            int arg[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { best[e] = -1.f; arg[e] = 0; }   // relu output >= 0 > -1
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int hi = 2 * ho - 1 + t / 3, wi = 2 * wo - 1 + t % 3;
+                if ((unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W) {
+                    float f[8];
+                    unpack8(*reinterpret_cast<const uint4*>(xg + (((int64_t)n * d.H + hi) * d.W + wi) * d.ldx + c), f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = fmaxf(fmaf(f[e], sc[e], sh[e]), 0.f);
+                        if (v > best[e]) { best[e] = v; arg[e] = t; }
+                    }
+                }
+            }
+            const uint4 ov = pack8(best);
+            *reinterpret_cast<uint4*>(yg + m * d.ldy + c) = ov;
+            if (d.argmax) {
+                uint2 a;
+                a.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+                a.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
+                *reinterpret_cast<uint2*>(d.argmax + m * d.C + c) = a;
+            }
+            if (d.stat_acc) {
+                float g[8];
+                unpack8(ov, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { part[0][e] += g[e]; part[1][e] += g[e] * g[e]; }
+            }
+        }
+    }
+    if (d.stat_acc) block_colsum<CGB, 2>(part, red, d.stat_acc, d.C, blockIdx.x * CGB, 2 * d.C, blockIdx.y % DS_R);
+}
+
+// Gather form of the max-pool backward fused with the ReLU mask of norm0 and the S1/S2 sums
+// of its BatchNorm backward.  One thread per (conv0-output pixel, 8 channels).
+template <int CGB>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const dsaspp_maxpool_desc d) {
+    __shared__ float red[256 * 16];
+    constexpr int RB = 256 / CGB;
+    const int cx = threadIdx.x % CGB, ry = threadIdx.x / CGB;
+    const int c = (blockIdx.x * CGB + cx) * 8;
+    const bool act = c < d.C;
+    const int Ho = d.H / 2, Wo = d.W / 2;
+    const int64_t Mi = (int64_t)d.n_img * d.H * d.W;
+    float sc[8], sh[8], mu[8], rs[8], part[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; mu[e] = 0.f; rs[e] = 1.f; part[0][e] = 0.f; part[1][e] = 0.f; }
+    if (act) { load8f(d.scale + c, sc); load8f(d.shift + c, sh); load8f(d.mean + c, mu); load8f(d.rstd + c, rs); }
+    const u16* xg = reinterpret_cast<const u16*>(d.x);
+    const u16* dyg = reinterpret_cast<const u16*>(d.dy);
+    u16* drg = reinterpret_cast<u16*>(d.dr);
+    if (act) {
+        for (int64_t m = (int64_t)blockIdx.y * RB + ry; m < Mi; m += (int64_t)gridDim.y * RB) {
+            const int n = (int)(m / (d.H * d.W));
+            const int rem = (int)(m - (int64_t)n * d.H * d.W);
+            const int h = rem / d.W, w = rem - h * d.W;
+            float g[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = 0.f;
+            // windows (ho, wo) that contain (h, w): 2*ho-1 <= h <= 2*ho+1
+            const int ho0 = h >> 1, ho1 = (h + 1) >> 1;
+            const int wo0 = w >> 1, wo1 = (w + 1) >> 1;
+            for (int ho = ho0; ho <= ho1; ++ho) {
+                if (ho >= Ho) continue;
+                for (int wo = wo0; wo <= wo1; ++wo) {
+                    if (wo >= Wo) continue;
+                    const int t = (h - (2 * ho - 1)) * 3 + (w - (2 * wo - 1));
+                    const int64_t mo = ((int64_t)n * Ho + ho) * Wo + wo;
+                    const uint2 a = *reinterpret_cast<const uint2*>(d.argmax + mo * d.C + c);
+                    float dyv[8];
+                    unpack8(*reinterpret_cast<const uint4*>(dyg + mo * d.lddy + c), dyv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int ae = ((e < 4 ? a.x : a.y) >> (8 * (e & 3))) & 0xff;
+                        if (ae == t) g[e] += dyv[e];
+                    }
+                }
+            }
+            float x[8];
+            unpack8(*reinterpret_cast<const uint4*>(xg + m * d.ldx + c), x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float pre = fmaf(x[e], sc[e], sh[e]);
+                if (!(pre > 0.f)) g[e] = 0.f;
+                part[0][e] += g[e];
+                part[1][e] += g[e] * ((x[e] - mu[e]) * rs[e]);
+            }
+            *reinterpret_cast<uint4*>(drg + m * d.lddr + c) = pack8(g);
+        }
+    }
+    if (d.s_acc) block_colsum<CGB, 2>(part, red, d.s_acc, d.C, blockIdx.x * CGB, 2 * d.C, blockIdx.y % DS_R);
+}
+
+inline dim3 row_grid(int C, int64_t M, int cgb) {
+    const int cg = (C + 7) / 8;
+    const int gx = (cg + cgb - 1) / cgb;
+    const int rb = 256 / cgb;
+    int64_t gy = (M + rb - 1) / rb;
+    const int64_t cap = (4096 + gx - 1) / gx;
+    if (gy > cap) gy = cap;
+    if (gy < 1) gy = 1;
+    return dim3(gx, (unsigned)gy);
+}
+
+#define ROW_DISPATCH(KERN, C, M, desc, s)                                                   \
+    do {                                                                                    \
+        if ((C) <= 64) {                                                                    \
+            hipLaunchKernelGGL(KERN<8>, row_grid((C), (M), 8), dim3(256), 0, s, desc);      \
+        } else {                                                                            \
+            hipLaunchKernelGGL(KERN<32>, row_grid((C), (M), 32), dim3(256), 0, s, desc);    \
+        }                                                                                   \
+    } while (0)
+
+}  // namespace
+
+extern "C" int dsaspp_bn_finalize(const dsaspp_bn_desc* d, dsaspp_stream_t stream) {
+    DS_REQUIRE(d && d->C > 0, "bn_finalize: bad descriptor");
+    if (d->use_running) DS_REQUIRE(d->running_mean && d->running_var, "bn_finalize: running stats missing");
+    else DS_REQUIRE(d->mean && d->var && d->rstd && d->count > 0.f, "bn_finalize: batch statistic buffers missing");
+    if (d->scale) DS_REQUIRE(d->shift != nullptr, "bn_finalize: shift missing");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d);
+    DS_LAUNCH_CHECK("bn_finalize");
+    return 0;
+}
+
+extern "C" int dsaspp_bn_bwd_finalize(const dsaspp_bn_bwd_desc* d, dsaspp_stream_t stream) {
+    DS_REQUIRE(d && d->C > 0 && d->acc && d->scale && d->count > 0.f, "bn_bwd_finalize: bad descriptor");
+    if (d->mode == 0) DS_REQUIRE(d->coefA && d->coefB && d->coefC && d->mean && d->rstd, "bn_bwd_finalize: coefficient buffers missing");
+    else DS_REQUIRE(d->corr1 && d->corr2, "bn_bwd_finalize: correction buffers missing");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d);
+    DS_LAUNCH_CHECK("bn_bwd_finalize");
+    return 0;
+}
+
+extern "C" int dsaspp_bn_act(const dsaspp_bnact_desc* d, dsaspp_stream_t stream) {
+    DS_REQUIRE(d && d->M > 0 && d->C > 0 && d->C % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0, "bn_act: bad descriptor");
+    DS_REQUIRE(d->x && d->y, "bn_act: null tensor");
+    ROW_DISPATCH(bn_act_kernel, d->C, d->M, *d, (hipStream_t)stream);
+    DS_LAUNCH_CHECK("bn_act");
+    return 0;
+}
+
+extern "C" int dsaspp_grad_extract(const dsaspp_gradx_desc* d, dsaspp_stream_t stream) {
+    DS_REQUIRE(d && d->M > 0 && d->C > 0 && d->C % 8 == 0 && d->ldg % 4 == 0 && d->lddz % 8 == 0, "grad_extract: bad descriptor");
+    DS_REQUIRE(d->g && d->dz, "grad_extract: null tensor");
+    if (d->corr1) DS_REQUIRE(d->corr2 && d->xs && d->s_mean && d->s_rstd && d->ldxs % 8 == 0, "grad_extract: correction inputs missing");
+    if (d->relu || d->s_acc) DS_REQUIRE(d->yref && d->ldyref % 8 == 0, "grad_extract: yref missing");
+    if (d->s_acc) DS_REQUIRE(d->r_mean && d->r_rstd, "grad_extract: r_mean/r_rstd missing");
+    if (d->mask) DS_REQUIRE(d->hw > 0 && d->mask_ld % 4 == 0, "grad_extract: mask needs hw");
+    ROW_DISPATCH(grad_extract_kernel, d->C, d->M, *d, (hipStream_t)stream);
+    DS_LAUNCH_CHECK("grad_extract");
+    return 0;
+}
+
+extern "C" int dsaspp_bn_bwd_apply(const dsaspp_bnapply_desc* d, dsaspp_stream_t stream) {
+    DS_REQUIRE(d && d->M > 0 && d->C > 0 && d->C % 8 == 0 && d->lddr % 8 == 0 && d->ldy % 8 == 0 && d->lddy % 8 == 0, "bn_bwd_apply: bad descriptor");
+    DS_REQUIRE(d->dr && d->y && d->dy && d->coefA && d->coefB && d->coefC, "bn_bwd_apply: null tensor");
+    ROW_DISPATCH(bn_apply_kernel, d->C, d->M, *d, (hipStream_t)stream);
+    DS_LAUNCH_CHECK("bn_bwd_apply");
+    return 0;
+}
+
+extern "C" int dsaspp_avgpool2_fwd(const dsaspp_pool_desc* d, dsaspp_stream_t stream) {
+    DS_REQUIRE(d && d->n_img > 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0, "avgpool2_fwd: H and W must be even");
+    DS_REQUIRE(d->C > 0 && d->C % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->x && d->y, "avgpool2_fwd: bad descriptor");
+    const int64_t Mo = (int64_t)d->n_img * (d->H / 2) * (d->W / 2);
+    ROW_DISPATCH(avgpool_fwd_kernel, d->C, Mo, *d, (hipStream_t)stream);
+    DS_LAUNCH_CHECK("avgpool2_fwd");
+    return 0;
+}
+
+extern "C" int dsaspp_avgpool2_bwd(const dsaspp_pool_desc* d, dsaspp_stream_t stream) {
+    DS_REQUIRE(d && d->n_img > 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0, "avgpool2_bwd: H and W must be even");
+    DS_REQUIRE(d->C > 0 && d->C % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->x && d->y, "avgpool2_bwd: bad descriptor");
+    const int64_t Mi = (int64_t)d->n_img * d->H * d->W;
+    ROW_DISPATCH(avgpool_bwd_kernel, d->C, Mi, *d, (hipStream_t)stream);
+    DS_LAUNCH_CHECK("avgpool2_bwd");
+    return 0;
+}
+
+extern "C" int dsaspp_stem_im2col(const dsaspp_im2col_desc* d, dsaspp_stream_t stream) {
+    DS_REQUIRE(d && d->n_img > 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0, "stem_im2col: H and W must be even");
+    DS_REQUIRE(d->x && d->col && d->ldcol >= 152 && d->ldcol % 8 == 0, "stem_im2col: ldcol must be >= 152 and a multiple of 8");
+    const int64_t total = (int64_t)d->n_img * (d->H / 2) * (d->W / 2) * (d->ldcol / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d);
+    DS_LAUNCH_CHECK("stem_im2col");
+    return 0;
+}
+
+extern "C" int dsaspp_maxpool3s2_fwd(const dsaspp_maxpool_desc* d, dsaspp_stream_t stream) {
+    DS_REQUIRE(d && d->n_img > 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0, "maxpool3s2_fwd: H and W must be even");
+    DS_REQUIRE(d->C > 0 && d->C % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->x && d->y && d->scale && d->shift, "maxpool3s2_fwd: bad descriptor");
+    const int64_t Mo = (int64_t)d->n_img * (d->H / 2) * (d->W / 2);
+    ROW_DISPATCH(maxpool_fwd_kernel, d->C, Mo, *d, (hipStream_t)stream);
+    DS_LAUNCH_CHECK("maxpool3s2_fwd");
+    return 0;
+}
+
+extern "C" int dsaspp_maxpool3s2_bwd(const dsaspp_maxpool_desc* d, dsaspp_stream_t stream) {
+    DS_REQUIRE(d && d->n_img > 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0, "maxpool3s2_bwd: H and W must be even");
+    DS_REQUIRE(d->C > 0 && d->C % 8 == 0 && d->ldx % 8 == 0 && d->lddy % 8 == 0 && d->lddr % 8 == 0, "maxpool3s2_bwd: bad strides");
+    DS_REQUIRE(d->x && d->dy && d->dr && d->argmax && d->scale && d->shift && d->mean && d->rstd, "maxpool3s2_bwd: null tensor");
+    const int64_t Mi = (int64_t)d->n_img * d->H * d->W;
+    ROW_DISPATCH(maxpool_bwd_kernel, d->C, Mi, *d, (hipStream_t)stream);
+    DS_LAUNCH_CHECK("maxpool3s2_bwd");
+    return 0;
+}

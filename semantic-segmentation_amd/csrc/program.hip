@@ -1,0 +1,139 @@
+// Error reporting and the recorded-program runner of libdsaspp (host side only).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+int dsaspp_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+extern "C" int dsaspp_version(void) { return 1; }
+extern "C" const char* dsaspp_last_error(void) { return g_err; }
+
+namespace {
+union AnyDesc {
+    dsaspp_conv_desc conv;
+    dsaspp_wgrad_desc wgrad;
+    dsaspp_bn_desc bn;
+    dsaspp_bn_bwd_desc bnb;
+    dsaspp_bnact_desc bnact;
+    dsaspp_gradx_desc gradx;
+    dsaspp_bnapply_desc bnapply;
+    dsaspp_pool_desc pool;
+    dsaspp_im2col_desc im2col;
+    dsaspp_maxpool_desc maxpool;
+    dsaspp_ce_desc ce;
+    dsaspp_up_desc up;
+    dsaspp_generic_desc gen;
+};
+struct Op {
+    int32_t kind;
+    AnyDesc d;
+};
+size_t desc_size(int32_t op) {
+    switch (op) {
+        case DSASPP_OP_CONV: return sizeof(dsaspp_conv_desc);
+        case DSASPP_OP_WGRAD: return sizeof(dsaspp_wgrad_desc);
+        case DSASPP_OP_BN_FINALIZE: return sizeof(dsaspp_bn_desc);
+        case DSASPP_OP_BN_BWD_FINALIZE: return sizeof(dsaspp_bn_bwd_desc);
+        case DSASPP_OP_BN_ACT: return sizeof(dsaspp_bnact_desc);
+        case DSASPP_OP_GRAD_EXTRACT: return sizeof(dsaspp_gradx_desc);
+        case DSASPP_OP_BN_BWD_APPLY: return sizeof(dsaspp_bnapply_desc);
+        case DSASPP_OP_AVGPOOL_FWD:
+        case DSASPP_OP_AVGPOOL_BWD: return sizeof(dsaspp_pool_desc);
+        case DSASPP_OP_IM2COL: return sizeof(dsaspp_im2col_desc);
+        case DSASPP_OP_MAXPOOL_FWD:
+        case DSASPP_OP_MAXPOOL_BWD: return sizeof(dsaspp_maxpool_desc);
+        case DSASPP_OP_UPCE:
+        case DSASPP_OP_CE_FINALIZE: return sizeof(dsaspp_ce_desc);
+        case DSASPP_OP_UP_FWD:
+        case DSASPP_OP_UP_BWD:
+        case DSASPP_OP_UP_ARGMAX: return sizeof(dsaspp_up_desc);
+        case DSASPP_OP_MEMSET:
+        case DSASPP_OP_COPY2D:
+        case DSASPP_OP_COPY2D_BF16: return sizeof(dsaspp_generic_desc);
+        default: return 0;
+    }
+}
+}  // namespace
+
+struct dsaspp_program {
+    std::vector<Op> ops;
+};
+
+extern "C" dsaspp_program* dsaspp_program_create(void) { return new (std::nothrow) dsaspp_program(); }
+extern "C" void dsaspp_program_destroy(dsaspp_program* p) { delete p; }
+extern "C" int dsaspp_program_size(const dsaspp_program* p) { return p ? (int)p->ops.size() : 0; }
+
+extern "C" int dsaspp_program_add(dsaspp_program* p, int32_t op, const void* desc, int64_t desc_bytes) {
+    DS_REQUIRE(p && desc, "program_add: null argument");
+    const size_t want = desc_size(op);
+    DS_REQUIRE(want != 0, "program_add: unknown op %d", op);
+    DS_REQUIRE((size_t)desc_bytes == want, "program_add: op %d descriptor is %lld bytes, library expects %zu (header mismatch)", op, (long long)desc_bytes, want);
+    Op o;
+    o.kind = op;
+    memset(&o.d, 0, sizeof(o.d));
+    memcpy(&o.d, desc, want);
+    try {
+        p->ops.push_back(o);
+    } catch (...) {
+        return dsaspp_set_error("program_add: out of memory");
+    }
+    return 0;
+}
+
+extern "C" int dsaspp_program_run(dsaspp_program* p, int32_t first, int32_t last, dsaspp_stream_t s) {
+    DS_REQUIRE(p, "program_run: null program");
+    const int n = (int)p->ops.size();
+    if (last < 0 || last > n) last = n;
+    DS_REQUIRE(first >= 0 && first <= last, "program_run: bad range [%d, %d)", first, last);
+    for (int i = first; i < last; ++i) {
+        const Op& o = p->ops[i];
+        int rc = 0;
+        switch (o.kind) {
+            case DSASPP_OP_CONV: rc = dsaspp_conv_fwd(&o.d.conv, s); break;
+            case DSASPP_OP_WGRAD: rc = dsaspp_conv_wgrad(&o.d.wgrad, s); break;
+            case DSASPP_OP_BN_FINALIZE: rc = dsaspp_bn_finalize(&o.d.bn, s); break;
+            case DSASPP_OP_BN_BWD_FINALIZE: rc = dsaspp_bn_bwd_finalize(&o.d.bnb, s); break;
+            case DSASPP_OP_BN_ACT: rc = dsaspp_bn_act(&o.d.bnact, s); break;
+            case DSASPP_OP_GRAD_EXTRACT: rc = dsaspp_grad_extract(&o.d.gradx, s); break;
+            case DSASPP_OP_BN_BWD_APPLY: rc = dsaspp_bn_bwd_apply(&o.d.bnapply, s); break;
+            case DSASPP_OP_AVGPOOL_FWD: rc = dsaspp_avgpool2_fwd(&o.d.pool, s); break;
+            case DSASPP_OP_AVGPOOL_BWD: rc = dsaspp_avgpool2_bwd(&o.d.pool, s); break;
+            case DSASPP_OP_IM2COL: rc = dsaspp_stem_im2col(&o.d.im2col, s); break;
+            case DSASPP_OP_MAXPOOL_FWD: rc = dsaspp_maxpool3s2_fwd(&o.d.maxpool, s); break;
+            case DSASPP_OP_MAXPOOL_BWD: rc = dsaspp_maxpool3s2_bwd(&o.d.maxpool, s); break;
+            case DSASPP_OP_UPCE: rc = dsaspp_upsample8_ce(&o.d.ce, s); break;
+            case DSASPP_OP_CE_FINALIZE: rc = dsaspp_ce_finalize(&o.d.ce, s); break;
+            case DSASPP_OP_UP_FWD: rc = dsaspp_upsample8_fwd(&o.d.up, s); break;
+            case DSASPP_OP_UP_BWD: rc = dsaspp_upsample8_bwd(&o.d.up, s); break;
+            case DSASPP_OP_UP_ARGMAX: rc = dsaspp_upsample8_argmax(&o.d.up, s); break;
+            case DSASPP_OP_MEMSET: rc = dsaspp_memset_async(o.d.gen.dst, o.d.gen.value, o.d.gen.n, s); break;
+            case DSASPP_OP_COPY2D:
+                rc = dsaspp_copy2d_f32((const float*)o.d.gen.src, o.d.gen.lds, (float*)o.d.gen.dst, o.d.gen.ldd, o.d.gen.rows,
+                                       o.d.gen.cols, o.d.gen.dst_cols, o.d.gen.accumulate, s);
+                break;
+            case DSASPP_OP_COPY2D_BF16:
+                rc = dsaspp_copy2d_f32_bf16((const float*)o.d.gen.src, o.d.gen.lds, o.d.gen.dst, o.d.gen.ldd, o.d.gen.rows,
+                                            o.d.gen.cols, o.d.gen.dst_cols, s);
+                break;
+            default: rc = dsaspp_set_error("program_run: unknown op %d at %d", o.kind, i);
+        }
+        if (rc != 0) {
+            char tmp[400];
+            snprintf(tmp, sizeof(tmp), "%s", g_err);
+            return dsaspp_set_error("program op %d (kind %d): %s", i, o.kind, tmp);
+        }
+    }
+    return 0;
+}

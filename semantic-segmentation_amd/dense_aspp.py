@@ -1,0 +1,326 @@
+"""DenseASPP nn.Module whose forward/backward run on the MI355X kernels of libdsaspp.so.
+
+Drop-in surface (reference call sites): ``from denseASPP import DenseASPP``
+(graph_seg_test.py:12); ``DenseASPP(args, model_cfg=cfg)`` (graph_seg_test.py:129) and the
+upstream ``DenseASPP(model_cfg, n_class=19, output_stride=8)``; ``nn.DataParallel(model,
+device_ids=[gpu])`` (graph_seg_test.py:131, graph_seg_main.py:173); ``state_dict`` /
+``load_state_dict`` with or without the ``module.`` prefix (graph_seg_main.py:198,279,
+graph_seg_test.py:135); ``train()/eval()/cuda()``; ``model(image) -> NCHW logits``
+(graph_seg_main.py:237, graph_seg_test.py:144) usable with CrossEntropyLoss / softmax.
+
+The module tree mirrors a plain PyTorch DenseASPP so that parameter and buffer names,
+shapes and values are checkpoint compatible, but the child modules only *hold* tensors:
+all arithmetic is recorded by engine.Engine and executed by the HIP library.  The
+parameters are views into one flat fp32 arena (arena.ParamArena).
+"""
+import re
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import spec as S
+from .arena import ParamArena
+from .engine import Engine
+
+_LEGACY = re.compile(r'\.(norm|relu|conv)\.(\d)\.')
+
+
+def _holder_layer(cin, mid, growth, dil):
+    m = nn.Module()
+    m.norm1 = nn.BatchNorm2d(cin)
+    m.relu1 = nn.ReLU(inplace=True)
+    m.conv1 = nn.Conv2d(cin, mid, 1, bias=False)
+    m.norm2 = nn.BatchNorm2d(mid)
+    m.relu2 = nn.ReLU(inplace=True)
+    m.conv2 = nn.Conv2d(mid, growth, 3, dilation=dil, padding=dil, bias=False)
+    return m
+
+
+def _holder_aspp(cin, d0, d1, rate, bn_start):
+    m = nn.Module()
+    if bn_start:
+        m.norm1 = nn.BatchNorm2d(cin, momentum=0.0003)
+    m.relu1 = nn.ReLU(inplace=True)
+    m.conv1 = nn.Conv2d(cin, d0, 1)
+    m.norm2 = nn.BatchNorm2d(d0, momentum=0.0003)
+    m.relu2 = nn.ReLU(inplace=True)
+    m.conv2 = nn.Conv2d(d0, d1, 3, dilation=rate, padding=rate)
+    return m
+
+
+class _LogitsFn(torch.autograd.Function):
+    """Autograd bridge for the plain ``model(x)`` API (full-resolution logits)."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        eng = model._run_forward(x)
+        eng.prog_up_fwd().run()
+        ctx.model, ctx.eng = model, eng
+        sp = model.spec
+        return eng.out_logits.view(eng.B, sp.n_class, eng.H, eng.W).clone()
+
+    @staticmethod
+    def backward(ctx, grad):
+        model, eng = ctx.model, ctx.eng
+        if not eng.training:
+            raise RuntimeError('DenseASPP: backward needs the forward pass to run in train() mode')
+        prog = eng.prog_up_bwd()
+        eng.grad_full.view(grad.shape).copy_(grad)
+        saved = model._gflat
+        # gradients of this pass only: autograd does the accumulation into .grad
+        model._gflat_zero()
+        prog.run()
+        eng._bwd.run()
+        g = saved.clone()
+        grads = [model.arena.view(g, n) for n in model._param_names]
+        return (None, None) + tuple(grads)
+
+
+class DenseASPP(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        model_cfg, n_class, output_stride = self._parse_ctor(args, kwargs)
+        sp = S.NetSpec(model_cfg, n_class, output_stride)
+        self.spec = sp
+        cs = sp.c_stem
+
+        feats = OrderedDict()
+        feats['conv0'] = nn.Conv2d(3, cs, 7, stride=2, padding=3, bias=False)
+        feats['norm0'] = nn.BatchNorm2d(cs)
+        feats['relu0'] = nn.ReLU(inplace=True)
+        feats['pool0'] = nn.MaxPool2d(3, stride=2, padding=1)
+        self.features = nn.Sequential(feats)
+        for blk in sp.blocks:
+            block = nn.Sequential()
+            for i, l in enumerate(blk.layers):
+                block.add_module('denselayer%d' % (i + 1), _holder_layer(l.cin, l.mid, l.growth, l.dil))
+            self.features.add_module('denseblock%d' % blk.index, block)
+            tr = nn.Sequential()
+            tr.add_module('norm', nn.BatchNorm2d(blk.C))
+            tr.add_module('relu', nn.ReLU(inplace=True))
+            tr.add_module('conv', nn.Conv2d(blk.C, blk.cout, 1, bias=False))
+            if blk.pool_after:
+                tr.add_module('pool', nn.AvgPool2d(2, stride=2))
+            self.features.add_module('transition%d' % blk.index, tr)
+        self.features.add_module('norm5', nn.BatchNorm2d(sp.c_feat))
+        for a in sp.aspp:
+            setattr(self, a.prefix, _holder_aspp(a.cin, a.d0, a.d1, a.rate, a.bn_start))
+        self.classification = nn.Sequential(
+            nn.Dropout2d(p=sp.dropout1),
+            nn.Conv2d(sp.C_aspp, n_class, 1),
+            nn.Upsample(scale_factor=8, mode='bilinear'))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight.data)
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+        # ---- arena bookkeeping
+        self.arena = ParamArena()
+        self._param_names = []
+        self.bn_modules = {}
+        for name, p in self.named_parameters():
+            self._param_names.append(name)
+            if p.dim() == 4:
+                if name == 'features.conv0.weight':
+                    self.arena.add(name, p.shape, 'stem')
+                elif name == 'classification.1.weight':
+                    self.arena.add(name, p.shape, 'conv', pad_rows=S.CLS_PAD)
+                else:
+                    self.arena.add(name, p.shape, 'conv')
+            elif name == 'classification.1.bias':
+                self.arena.add(name, p.shape, 'vec', pad_rows=S.CLS_PAD)
+            else:
+                self.arena.add(name, p.shape, 'vec')
+        for name, m in self.named_modules():
+            if isinstance(m, nn.BatchNorm2d):
+                self.bn_modules[name] = m
+        self._flat = None
+        self._gflat = None
+        self._w16 = None
+        self._wt16 = None
+        self._w0_16 = None
+        self._wt_table = None
+        self._buffers_flat = {}
+        self._engines = {}
+        self._backend = None
+        self._flatten()
+        self._register_load_state_dict_pre_hook(self._remap_keys)
+
+    # ------------------------------------------------------------------ construction helpers
+    @staticmethod
+    def _parse_ctor(args, kwargs):
+        """Accept DenseASPP(model_cfg, n_class=19, output_stride=8) and DenseASPP(args, model_cfg=cfg)."""
+        args = list(args)
+        cfg = kwargs.pop('model_cfg', None)
+        if cfg is None:
+            if not args or not isinstance(args[0], dict):
+                raise TypeError('DenseASPP needs a model_cfg dict (positional, or model_cfg=...)')
+            cfg = args.pop(0)
+        elif args and not isinstance(args[0], dict):
+            args.pop(0)        # the reference passes its argparse namespace first; nothing in it is used
+        n_class = kwargs.pop('n_class', args.pop(0) if args else 19)
+        output_stride = kwargs.pop('output_stride', args.pop(0) if args else 8)
+        if kwargs or args:
+            raise TypeError('DenseASPP: unexpected arguments %r %r' % (args, kwargs))
+        return cfg, int(n_class), int(output_stride)
+
+    @staticmethod
+    def _remap_keys(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Accept checkpoints saved from a DataParallel wrapper and legacy dotted child names."""
+        for k in list(state_dict.keys()):
+            nk = k
+            if prefix == '' and nk.startswith('module.'):
+                nk = nk[len('module.'):]
+            nk = _LEGACY.sub(lambda m: '.%s%s.' % (m.group(1), m.group(2)), nk)
+            if nk != k:
+                state_dict[nk] = state_dict.pop(k)
+
+    def _flatten(self):
+        """(Re)build the flat arenas on the device the parameters currently live on."""
+        dev = self.features.conv0.weight.device
+        for p in self.parameters():
+            if p.dtype != torch.float32:
+                raise TypeError('DenseASPP keeps fp32 master parameters; the kernels compute in bf16 with fp32 accumulation')
+        flat = self.arena.allocate(dev)
+        named = dict(self.named_parameters())
+        for name in self._param_names:
+            v = self.arena.view(flat, name)
+            v.copy_(named[name].data)
+            named[name].data = v
+        self._flat = flat
+        self._gflat = torch.zeros_like(flat)
+        self._alloc_shadows()
+        self._buffers_flat = {n: b for n, b in self.named_buffers()}
+        self._engines = {}
+        self._wt_table = None
+        for name in self._param_names:
+            named[name].grad = None
+
+    def _alloc_shadows(self):
+        dt = self._backend.act_dtype if self._backend is not None else torch.bfloat16
+        dev = self._flat.device
+        self._w16 = torch.zeros(self.arena.size, dtype=dt, device=dev)
+        self._wt16 = torch.zeros(max(self.arena.tsize, 8), dtype=dt, device=dev)
+        self._w0_16 = torch.zeros(self.spec.c_stem * S.STEM_KPAD, dtype=dt, device=dev)
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        self._flatten()
+        return self
+
+    def _check_arena(self):
+        p = self.features.conv0.weight
+        if (self._flat is None or p.device != self._flat.device
+                or p.data_ptr() != self._flat.data_ptr() + 4 * self.arena.by_name['features.conv0.weight'].off
+                or self.classification[1].bias.data_ptr() != self._flat.data_ptr() + 4 * self.arena.by_name['classification.1.bias'].off):
+            self._flatten()
+
+    def _replicate_for_data_parallel(self):
+        raise RuntimeError('DenseASPP (MI355X) runs one process per GPU: wrap it as nn.DataParallel(model, device_ids=[gpu]) '
+                           'or launch one rank per device and use semantic_segmentation_amd.distributed; '
+                           'multi-device nn.DataParallel replication is not supported')
+
+    def bind_grads(self):
+        """Point every Parameter's .grad at its slice of the flat gradient arena."""
+        named = dict(self.named_parameters())
+        for name in self._param_names:
+            named[name].grad = self.arena.view(self._gflat, name)
+
+    def _gflat_zero(self):
+        self._gflat.zero_()
+
+    # ------------------------------------------------------------------ backend / engines
+    def _get_backend(self):
+        if self._backend is None:
+            from .backend import HipBackend
+            self._backend = HipBackend()
+        return self._backend
+
+    def set_backend(self, backend):
+        """Test hook: run descriptor lists through another interpreter (CPU kernel model in tests/)."""
+        self._backend = backend
+        self._engines = {}
+        self._alloc_shadows()
+
+    def engine(self, batch, height, width, training=None):
+        training = self.training if training is None else training
+        key = (batch, height, width, bool(training))
+        eng = self._engines.get(key)
+        if eng is None:
+            self._check_arena()
+            eng = Engine(self, batch, height, width, bool(training), self._get_backend(), self._flat.device)
+            eng.programs()
+            self._engines[key] = eng
+        return eng
+
+    def refresh_weights(self):
+        """bf16 shadow copies of the master weights: forward layout, padded stem rows, transposed copies."""
+        be = self._get_backend()
+        be.refresh_weights(self)
+
+    # ------------------------------------------------------------------ passes
+    def _run_forward(self, x, dropout_masks=None, generator=None, refresh=True):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError('DenseASPP expects an N x 3 x H x W image batch, got %s' % (tuple(x.shape),))
+        if not x.is_floating_point():
+            raise TypeError('DenseASPP expects a floating point image batch')
+        self._check_arena()
+        if x.device != self._flat.device:
+            raise RuntimeError('input is on %s but the model is on %s' % (x.device, self._flat.device))
+        B, _, H, W = x.shape
+        eng = self.engine(B, H, W)
+        if refresh:
+            self.refresh_weights()
+        eng.set_input(x.detach().to(torch.float32))
+        if eng.training:
+            eng.draw_dropout(generator=generator, masks=dropout_masks)
+        eng._fwd.run()
+        return eng
+
+    def forward(self, x):
+        """Full-resolution logits N x n_class x H x W (fp32), differentiable w.r.t. the parameters."""
+        if torch.is_grad_enabled() and self.training:
+            params = [p for _, p in self.named_parameters()]
+            return _LogitsFn.apply(self, x, *params)
+        eng = self._run_forward(x)
+        eng.prog_up_fwd().run()
+        sp = self.spec
+        return eng.out_logits.view(eng.B, sp.n_class, eng.H, eng.W).clone()
+
+    def forward_lowres(self, x, dropout_masks=None):
+        """Logits at 1/8 resolution, N x n_class x H/8 x W/8 fp32 (no autograd)."""
+        eng = self._run_forward(x, dropout_masks=dropout_masks)
+        lg = eng.logits.view(eng.B, eng.H2, eng.W2, S.CLS_PAD)[..., :self.spec.n_class]
+        return lg.permute(0, 3, 1, 2).contiguous()
+
+    def predict(self, x):
+        """Arg-max class per pixel, N x H x W int64 (fused upsample + argmax, eval-style)."""
+        eng = self._run_forward(x)
+        eng.prog_argmax().run()
+        return eng.out_argmax.view(eng.B, eng.H, eng.W).clone()
+
+    def train_step(self, x, labels, ignore_index=255, dropout_masks=None, generator=None, zero_grad=True,
+                   refresh=True):
+        """Fused forward + bilinear-x8/cross-entropy + backward.  Leaves gradients in the flat gradient
+        arena (every Parameter's .grad is a view of it) and returns the mean loss as a 1-element tensor."""
+        if not self.training:
+            raise RuntimeError('train_step needs train() mode')
+        if zero_grad:
+            self._gflat_zero()
+        eng = self._run_forward(x, dropout_masks=dropout_masks, generator=generator, refresh=refresh)
+        if eng._loss_ignore != ignore_index:
+            eng._fwd_loss = eng.backend.compile(eng.build_loss(ignore_index=ignore_index))
+            eng._loss_ignore = ignore_index
+        eng.set_labels(labels)
+        eng._fwd_loss.run()
+        eng._bwd.run()
+        if self.features.conv0.weight.grad is None or \
+                self.features.conv0.weight.grad.data_ptr() != self._gflat.data_ptr() + 4 * self.arena.by_name['features.conv0.weight'].off:
+            self.bind_grads()
+        return eng.loss
+
+    def conv_macs(self, height, width):
+        return self.spec.conv_macs(height, width)

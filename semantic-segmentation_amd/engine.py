@@ -1,0 +1,635 @@
+"""Execution planner for the DenseASPP forward/backward path.
+
+For one (batch, height, width, training) configuration the Engine owns every activation
+buffer (feature slabs, bottleneck tensors, gradient slabs, statistics) and records the
+forward and backward passes once as flat lists of kernel descriptors -- the same
+descriptors include/dsaspp.h defines.  A backend turns a list into something runnable:
+the product backend (HipBackend) copies the descriptors into a dsaspp_program inside
+libdsaspp.so and replays it with one C call per pass; tests substitute a backend that
+interprets the same descriptors on the CPU to check the orchestration without a GPU.
+
+What replaces what (reference call sites):
+  * torch.cat in every dense layer / ASPP branch -> convolutions write their g (or d1)
+    output channels straight into the block's NHWC feature slab (graph_seg_main.py:237)
+  * BatchNorm2d + ReLU in front of every conv -> per-consumer scale/shift tables applied in
+    the conv prologue; batch statistics come from sums taken in the producer's epilogue
+  * loss.backward() (graph_seg_main.py:239) -> per layer: weight gradient with the prologue
+    recomputed, data gradient accumulated into an fp32 gradient slab.  BatchNorm backward
+    of the shared slab is made single-pass: each consumer adds scale*dy and keeps
+    (sum dy, sum dy*xhat); the mean terms are folded into two per-channel correction
+    vectors that are applied when the producing layer reads its gradient back.
+"""
+import torch
+
+from . import spec as S
+
+
+class Ref:
+    """A device tensor plus an element offset; what a descriptor pointer field holds."""
+    __slots__ = ('t', 'off')
+
+    def __init__(self, t, off=0):
+        self.t, self.off = t, int(off)
+
+    def __add__(self, k):
+        return Ref(self.t, self.off + int(k))
+
+    def ptr(self):
+        return self.t.data_ptr() + self.off * self.t.element_size()
+
+
+class OpList(list):
+    def op(self, kind, **fields):
+        self.append((kind, fields))
+
+
+def _r(t, off=0):
+    return Ref(t, off)
+
+
+class Slab:
+    """NHWC feature slab of one dense block (or the ASPP stack) with its statistics."""
+
+    def __init__(self, eng, M, C, H, W, train):
+        dev = eng.device
+        self.M, self.C, self.H, self.W = M, C, H, W
+        self.x = torch.zeros(M * C, dtype=eng.backend.act_dtype, device=dev)
+        self.mean = torch.zeros(C, dtype=torch.float32, device=dev)
+        self.var = torch.ones(C, dtype=torch.float32, device=dev)
+        self.rstd = torch.ones(C, dtype=torch.float32, device=dev)
+        if train:
+            self.g = torch.zeros(M * C, dtype=torch.float32, device=dev)
+            self.corr = torch.zeros(2 * C, dtype=torch.float32, device=dev)   # corr1 | corr2
+
+
+class Engine:
+    def __init__(self, model, batch, height, width, training, backend, device):
+        if height % 8 or width % 8:
+            raise ValueError('input height and width must be multiples of 8 (got %dx%d)' % (height, width))
+        self.model = model
+        self.spec = model.spec
+        self.arena = model.arena
+        self.B, self.H, self.W = batch, height, width
+        self.training = training
+        self.backend = backend
+        self.device = device
+        self.R = backend.stat_replicas
+        sp = self.spec
+        dev = device
+        f32, bf16 = torch.float32, backend.act_dtype
+        self.act_dtype = bf16
+
+        def zeros(n, dt=f32):
+            return torch.zeros(int(n), dtype=dt, device=dev)
+
+        self._zeros = zeros
+        B = batch
+        self.H0, self.W0 = height // 2, width // 2          # conv0 output
+        self.H1, self.W1 = height // 4, width // 4          # block 1
+        self.H2, self.W2 = height // 8, width // 8          # blocks 2-4, ASPP
+        self.M0, self.M1, self.M2 = B * self.H0 * self.W0, B * self.H1 * self.W1, B * self.H2 * self.W2
+
+        # ---- activations
+        self.x_in = zeros(B * 3 * height * width)
+        self.col = zeros(self.M0 * S.STEM_KPAD, bf16)
+        self.c0out = zeros(self.M0 * sp.c_stem, bf16)
+        self.slabs = []
+        for blk in sp.blocks:
+            M, H, W = (self.M1, self.H1, self.W1) if blk.index == 1 else (self.M2, self.H2, self.W2)
+            self.slabs.append(Slab(self, M, blk.C, H, W, training))
+        self.aslab = Slab(self, self.M2, sp.C_aspp, self.H2, self.W2, training)
+        self.t1tmp = zeros(self.M1 * sp.blocks[0].cout, bf16)
+        self.t4out = zeros(self.M2 * sp.c_feat, bf16)
+        self.logits = zeros(self.M2 * S.CLS_PAD)
+        # bottleneck tensors: kept per layer when training (needed by backward), shared otherwise
+        self.y1 = {}
+        shared = {}
+        for blk in sp.blocks:
+            M = self.M1 if blk.index == 1 else self.M2
+            for l in blk.layers:
+                if training:
+                    self.y1[l.prefix] = zeros(M * l.mid, bf16)
+                else:
+                    key = (M, l.mid)
+                    if key not in shared:
+                        shared[key] = zeros(M * l.mid, bf16)
+                    self.y1[l.prefix] = shared[key]
+        for a in sp.aspp:
+            if training:
+                self.y1[a.prefix] = zeros(self.M2 * a.d0, bf16)
+            else:
+                key = (self.M2, a.d0)
+                if key not in shared:
+                    shared[key] = zeros(self.M2 * a.d0, bf16)
+                self.y1[a.prefix] = shared[key]
+
+        # ---- per-BatchNorm tables: scale | shift | mean | var | rstd, C floats each
+        self.bn = {}
+        self.acc = {}
+        self._pending_zero = []
+
+        def bn_tables(name, C):
+            self.bn[name] = zeros(5 * C)
+
+        def accbuf(name, C):
+            self.acc[name] = zeros(self.R * 2 * C)
+
+        bn_tables('features.norm0', sp.c_stem)
+        accbuf('features.norm0', sp.c_stem)
+        accbuf('pool0', sp.c_stem)
+        for blk in sp.blocks:
+            for l in blk.layers:
+                bn_tables(l.prefix + '.norm1', l.cin)
+                bn_tables(l.prefix + '.norm2', l.mid)
+                accbuf(l.prefix + '.y1', l.mid)
+                accbuf(l.prefix + '.out', l.growth)
+                if training:
+                    accbuf(l.prefix + '.s1', l.cin)
+                    accbuf(l.prefix + '.s2', l.mid)
+            bn_tables(blk.trans_prefix + '.norm', blk.C)
+            accbuf(blk.trans_prefix + '.out', blk.cout)
+            if training:
+                accbuf(blk.trans_prefix + '.s', blk.C)
+        bn_tables('features.norm5', sp.c_feat)
+        accbuf('feat', sp.c_feat)
+        if training:
+            accbuf('features.norm5.s', sp.c_feat)
+        for a in sp.aspp:
+            if a.bn_start:
+                bn_tables(a.prefix + '.norm1', a.cin)
+                if training:
+                    accbuf(a.prefix + '.s1', a.cin)
+            bn_tables(a.prefix + '.norm2', a.d0)
+            accbuf(a.prefix + '.y1', a.d0)
+            accbuf(a.prefix + '.out', a.d1)
+            if training:
+                accbuf(a.prefix + '.s2', a.d0)
+
+        # ---- loss / backward temporaries
+        self.labels = torch.zeros(B * height * width, dtype=torch.int64, device=dev)
+        self.accum = zeros(4)
+        self.loss = zeros(1)
+        if training:
+            self.dlogits = zeros(self.M2 * S.CLS_PAD)
+            self.dlogits16 = zeros(self.M2 * S.CLS_PAD, bf16)
+            self.argmax0 = torch.zeros(self.M1 * sp.c_stem, dtype=torch.uint8, device=dev)
+            cmax_mid = max([l.mid for b in sp.blocks for l in b.layers] + [sp.d0])
+            big = max(self.M0 * sp.c_stem, self.M2 * sp.c_feat, self.M1 * sp.blocks[0].cout,
+                      self.M1 * cmax_mid, self.M2 * cmax_mid)
+            self.tmp_a = zeros(big, bf16)
+            self.tmp_b = zeros(big, bf16)
+            self.tmp_c = zeros(big, bf16)
+            self.coef = zeros(3 * max(sp.c_feat, cmax_mid, sp.c_stem))
+            self.dw0pad = zeros(sp.c_stem * S.STEM_KPAD)
+            n_drop = 5 * sp.d1 + sp.C_aspp
+            self.dropmask = torch.ones(B * n_drop, dtype=f32, device=dev)
+            self.drop_ld = n_drop
+        else:
+            self.dropmask = None
+        self.out_logits = None
+        self.out_argmax = None
+        self._fwd = None
+        self._bwd = None
+        self._fwd_loss = None
+        self._up_fwd = None
+        self._up_bwd = None
+        self._argmax = None
+
+    # ------------------------------------------------------------------ helpers
+    def P(self, name):
+        """Ref to a parameter in the fp32 arena."""
+        return Ref(self.model._flat, self.arena.by_name[name].off)
+
+    def PG(self, name):
+        return Ref(self.model._gflat, self.arena.by_name[name].off)
+
+    def W16(self, name):
+        return Ref(self.model._w16, self.arena.by_name[name].off)
+
+    def WT16(self, name):
+        return Ref(self.model._wt16, self.arena.by_name[name].toff)
+
+    def BUF(self, name):
+        return Ref(self.model._buffers_flat[name], 0)
+
+    def bnt(self, name, which, C, off=0):
+        """Ref into a BatchNorm table: which in scale/shift/mean/var/rstd."""
+        idx = ('scale', 'shift', 'mean', 'var', 'rstd').index(which)
+        return Ref(self.bn[name], idx * C + off)
+
+    def _bn_finalize(self, ops, name, C, slab=None, slab_off=0, acc=None, acc_c0=0, acc_cn=0, count=1.0,
+                     affine=True, want_scale=True):
+        """Record the forward BatchNorm bookkeeping for BatchNorm `name` over C channels."""
+        m = self.model.bn_modules.get(name)
+        use_running = not self.training
+        if slab is not None:
+            mean, var, rstd = _r(slab.mean, slab_off), _r(slab.var, slab_off), _r(slab.rstd, slab_off)
+        else:
+            mean, var, rstd = self.bnt(name, 'mean', C), self.bnt(name, 'var', C), self.bnt(name, 'rstd', C)
+        f = dict(C=C, acc=acc, acc_c0=acc_c0, acc_cn=acc_cn, count=float(count),
+                 mean=mean, var=var, rstd=rstd, use_running=int(use_running))
+        if affine and m is not None:
+            f.update(gamma=self.P(name + '.weight'), beta=self.P(name + '.bias'),
+                     running_mean=self.BUF(name + '.running_mean'), running_var=self.BUF(name + '.running_var'),
+                     num_batches_tracked=self.BUF(name + '.num_batches_tracked'),
+                     momentum=float(m.momentum), eps=float(m.eps))
+        else:
+            f.update(gamma=None, beta=None, running_mean=None, running_var=None, num_batches_tracked=None,
+                     momentum=0.0, eps=1e-5)
+        if want_scale:
+            f.update(scale=self.bnt(name, 'scale', C), shift=self.bnt(name, 'shift', C))
+        else:
+            f.update(scale=None, shift=None)
+        ops.op('bn_finalize', **f)
+
+    # ------------------------------------------------------------------ forward
+    def build_forward(self):
+        sp, tr = self.spec, self.training
+        ops = OpList()
+        B = self.B
+        conv = dict(in_scale=None, in_shift=None, in_relu=0, in_mask=None, in_mask_ld=0, bias=None,
+                    out_mask=None, out_mask_ld=0, y=None, ldy=0, y_f32=0, stat_acc=None, epi_relu=0, ref=None,
+                    ldref=0, e_scale=None, e_shift=None, e_mean=None, e_rstd=None, s_acc=None, g=None, ldg=0,
+                    g_accumulate=0)
+        self._conv_defaults = conv
+
+        def C(**kw):
+            d = dict(conv)
+            d.update(kw)
+            ops.op('conv', **d)
+
+        # ---- stem: im2col + GEMM, norm0 statistics, BN-ReLU-maxpool into slab 1
+        cs = sp.c_stem
+        ops.op('im2col', n_img=B, H=self.H, W=self.W, x=_r(self.x_in), col=_r(self.col), ldcol=S.STEM_KPAD)
+        C(n_img=B, H=self.H0, W=self.W0, cin=S.STEM_KPAD, cout=cs, taps=1, dil=1, x=_r(self.col), ldx=S.STEM_KPAD,
+          w=_r(self.model._w0_16), y=_r(self.c0out), ldy=cs, stat_acc=_r(self.acc['features.norm0']) if tr else None)
+        self._bn_finalize(ops, 'features.norm0', cs, acc=_r(self.acc['features.norm0']) if tr else None, acc_c0=0,
+                          acc_cn=cs if tr else 0, count=self.M0)
+        s1 = self.slabs[0]
+        ops.op('maxpool_fwd', n_img=B, H=self.H0, W=self.W0, C=cs, x=_r(self.c0out), ldx=cs,
+               scale=self.bnt('features.norm0', 'scale', cs), shift=self.bnt('features.norm0', 'shift', cs),
+               y=_r(s1.x), ldy=s1.C, argmax=_r(self.argmax0) if tr else None,
+               stat_acc=_r(self.acc['pool0']) if tr else None, dy=None, lddy=0, dr=None, lddr=0, mean=None, rstd=None,
+               s_acc=None)
+        pending = ('pool0', 0, cs)          # (acc name, first slab channel, count) still to be turned into mean/var
+
+        # ---- dense blocks + transitions
+        for bi, blk in enumerate(sp.blocks):
+            slab = self.slabs[bi]
+            M, H, W = slab.M, slab.H, slab.W
+            for l in blk.layers:
+                n1, n2 = l.prefix + '.norm1', l.prefix + '.norm2'
+                self._bn_finalize(ops, n1, l.cin, slab=slab, acc=_r(self.acc[pending[0]]) if tr else None,
+                                  acc_c0=pending[1], acc_cn=pending[2] if tr else 0, count=M)
+                y1 = self.y1[l.prefix]
+                C(n_img=B, H=H, W=W, cin=l.cin, cout=l.mid, taps=1, dil=1, x=_r(slab.x), ldx=slab.C,
+                  w=self.W16(l.prefix + '.conv1.weight'), in_scale=self.bnt(n1, 'scale', l.cin),
+                  in_shift=self.bnt(n1, 'shift', l.cin), in_relu=1, y=_r(y1), ldy=l.mid,
+                  stat_acc=_r(self.acc[l.prefix + '.y1']) if tr else None)
+                self._bn_finalize(ops, n2, l.mid, acc=_r(self.acc[l.prefix + '.y1']) if tr else None, acc_c0=0,
+                                  acc_cn=l.mid if tr else 0, count=M)
+                C(n_img=B, H=H, W=W, cin=l.mid, cout=l.growth, taps=9, dil=l.dil, x=_r(y1), ldx=l.mid,
+                  w=self.W16(l.prefix + '.conv2.weight'), in_scale=self.bnt(n2, 'scale', l.mid),
+                  in_shift=self.bnt(n2, 'shift', l.mid), in_relu=1, y=_r(slab.x, l.cin), ldy=slab.C,
+                  stat_acc=_r(self.acc[l.prefix + '.out']) if tr else None)
+                pending = (l.prefix + '.out', l.cin, l.growth)
+            # transition
+            nt = blk.trans_prefix + '.norm'
+            self._bn_finalize(ops, nt, blk.C, slab=slab, acc=_r(self.acc[pending[0]]) if tr else None,
+                              acc_c0=pending[1], acc_cn=pending[2] if tr else 0, count=M)
+            tacc = _r(self.acc[blk.trans_prefix + '.out']) if tr else None
+            common = dict(n_img=B, H=H, W=W, cin=blk.C, cout=blk.cout, taps=1, dil=1, x=_r(slab.x), ldx=slab.C,
+                          w=self.W16(blk.trans_prefix + '.conv.weight'), in_scale=self.bnt(nt, 'scale', blk.C),
+                          in_shift=self.bnt(nt, 'shift', blk.C), in_relu=1)
+            if blk.pool_after:
+                nxt = self.slabs[bi + 1]
+                C(y=_r(self.t1tmp), ldy=blk.cout, **common)
+                ops.op('avgpool_fwd', n_img=B, H=H, W=W, C=blk.cout, x=_r(self.t1tmp), ldx=blk.cout, y=_r(nxt.x),
+                       ldy=nxt.C, stat_acc=tacc)
+            elif bi + 1 < len(sp.blocks):
+                nxt = self.slabs[bi + 1]
+                C(y=_r(nxt.x), ldy=nxt.C, stat_acc=tacc, **common)
+            else:
+                C(y=_r(self.t4out), ldy=blk.cout, stat_acc=tacc, **common)
+            pending = (blk.trans_prefix + '.out', 0, blk.cout)
+
+        # ---- norm5 + ReLU into the ASPP slab; statistics of the result for the ASPP norm1 layers
+        cf, A = sp.c_feat, self.aslab
+        self._bn_finalize(ops, 'features.norm5', cf, acc=_r(self.acc[pending[0]]) if tr else None, acc_c0=0,
+                          acc_cn=cf if tr else 0, count=self.M2)
+        ops.op('bn_act', M=self.M2, C=cf, x=_r(self.t4out), ldx=cf, scale=self.bnt('features.norm5', 'scale', cf),
+               shift=self.bnt('features.norm5', 'shift', cf), relu=1, y=_r(A.x, sp.off_feat), ldy=A.C,
+               stat_acc=_r(self.acc['feat']) if tr else None)
+        if tr:
+            # statistics of the feature channels, shared by every later ASPP norm1
+            ops.op('bn_finalize', C=cf, acc=_r(self.acc['feat']), acc_c0=0, acc_cn=cf, count=float(self.M2),
+                   mean=_r(A.mean, sp.off_feat), var=_r(A.var, sp.off_feat), rstd=_r(A.rstd, sp.off_feat),
+                   gamma=None, beta=None, running_mean=None, running_var=None, num_batches_tracked=None,
+                   momentum=0.0, eps=1e-5, use_running=0, scale=None, shift=None)
+        pending = None
+        H, W, M = self.H2, self.W2, self.M2
+        for i, a in enumerate(sp.aspp):
+            y1 = self.y1[a.prefix]
+            n2 = a.prefix + '.norm2'
+            kw = dict(n_img=B, H=H, W=W, cin=a.cin, cout=a.d0, taps=1, dil=1, x=_r(A.x, a.off_in), ldx=A.C,
+                      w=self.W16(a.prefix + '.conv1.weight'), bias=self.P(a.prefix + '.conv1.bias'), y=_r(y1),
+                      ldy=a.d0, stat_acc=_r(self.acc[a.prefix + '.y1']) if tr else None)
+            if a.bn_start:
+                n1 = a.prefix + '.norm1'
+                self._bn_finalize(ops, n1, a.cin, slab=A, slab_off=a.off_in,
+                                  acc=_r(self.acc[pending[0]]) if tr else None, acc_c0=0,
+                                  acc_cn=pending[2] if tr else 0, count=M)
+                kw.update(in_scale=self.bnt(n1, 'scale', a.cin), in_shift=self.bnt(n1, 'shift', a.cin), in_relu=1)
+            # ASPP_3 reads ReLU(norm5(x)) as stored: its own ReLU is the identity on that data
+            C(**kw)
+            self._bn_finalize(ops, n2, a.d0, acc=_r(self.acc[a.prefix + '.y1']) if tr else None, acc_c0=0,
+                              acc_cn=a.d0 if tr else 0, count=M)
+            last = i == len(sp.aspp) - 1
+            C(n_img=B, H=H, W=W, cin=a.d0, cout=a.d1, taps=9, dil=a.rate, x=_r(y1), ldx=a.d0,
+              w=self.W16(a.prefix + '.conv2.weight'), bias=self.P(a.prefix + '.conv2.bias'),
+              in_scale=self.bnt(n2, 'scale', a.d0), in_shift=self.bnt(n2, 'shift', a.d0), in_relu=1,
+              out_mask=_r(self.dropmask, i * sp.d1) if tr else None, out_mask_ld=self.drop_ld if tr else 0,
+              y=_r(A.x, a.off_out), ldy=A.C, stat_acc=_r(self.acc[a.prefix + '.out']) if (tr and not last) else None)
+            pending = (a.prefix + '.out', 0, a.d1)
+        # ---- classifier (Dropout2d on its input in training) -> fp32 low-res logits
+        C(n_img=B, H=H, W=W, cin=sp.C_aspp, cout=S.CLS_PAD, taps=1, dil=1, x=_r(A.x), ldx=A.C,
+          w=self.W16('classification.1.weight'), bias=self.P('classification.1.bias'),
+          in_mask=_r(self.dropmask, 5 * sp.d1) if tr else None, in_mask_ld=self.drop_ld if tr else 0,
+          y=_r(self.logits), ldy=S.CLS_PAD, y_f32=1)
+        return ops
+
+    # ------------------------------------------------------------------ loss (fused upsample + CE)
+    def build_loss(self, ignore_index=255, grad_scale=1.0):
+        sp = self.spec
+        ops = OpList()
+        ce = dict(n_img=self.B, h=self.H2, w=self.W2, n_class=sp.n_class, ldl=S.CLS_PAD, logits=_r(self.logits),
+                  labels=_r(self.labels), ignore_index=int(ignore_index), dlogits=_r(self.dlogits),
+                  accum=_r(self.accum), grad_scale=float(grad_scale), loss=_r(self.loss),
+                  dlogits_bf16=_r(self.dlogits16), lddb=S.CLS_PAD, dbias=self.PG('classification.1.bias'))
+        ops.op('memset', src=None, dst=_r(self.dlogits), n=self.dlogits.numel() * 4, value=0, lds=0, ldd=0, rows=0,
+               cols=0, dst_cols=0, accumulate=0)
+        ops.op('memset', src=None, dst=_r(self.accum), n=16, value=0, lds=0, ldd=0, rows=0, cols=0, dst_cols=0,
+               accumulate=0)
+        ops.op('upce', **ce)
+        ops.op('ce_finalize', **ce)
+        return ops
+
+    # ------------------------------------------------------------------ backward
+    def build_backward(self):
+        """Backward pass from the low-resolution logit gradient (self.dlogits16, bf16 [M2][32])."""
+        assert self.training
+        sp = self.spec
+        ops = OpList()
+        B = self.B
+        conv = self._conv_defaults
+        A = self.aslab
+        H, W, M = self.H2, self.W2, self.M2
+
+        def C(**kw):
+            d = dict(conv)
+            d.update(kw)
+            ops.op('conv', **d)
+
+        def WG(**kw):
+            d = dict(in_scale=None, in_shift=None, in_relu=0, in_mask=None, in_mask_ld=0, ksplit=0)
+            d.update(kw)
+            ops.op('wgrad', **d)
+
+        def zero(t):
+            ops.op('memset', src=None, dst=_r(t), n=t.numel() * t.element_size(), value=0, lds=0, ldd=0, rows=0,
+                   cols=0, dst_cols=0, accumulate=0)
+
+        def gradx(**kw):
+            d = dict(hw=1, corr1=None, corr2=None, xs=None, ldxs=0, s_mean=None, s_rstd=None, mask=None, mask_ld=0,
+                     relu=0, yref=None, ldyref=0, r_scale=None, r_shift=None, r_mean=None, r_rstd=None, s_acc=None,
+                     colsum=None)
+            d.update(kw)
+            ops.op('grad_extract', **d)
+
+        def slab_extract(slab, c0, cn, dz, **kw):
+            """dz[M][cn] <- gradient of slab channels [c0, c0+cn) with the BatchNorm corrections applied."""
+            gradx(M=slab.M, C=cn, g=_r(slab.g, c0), ldg=slab.C, corr1=_r(slab.corr, c0), corr2=_r(slab.corr, slab.C + c0),
+                  xs=_r(slab.x, c0), ldxs=slab.C, s_mean=_r(slab.mean, c0), s_rstd=_r(slab.rstd, c0), dz=_r(dz), lddz=cn,
+                  **kw)
+
+        def bn_bwd(name, C_, acc, count, mode, slab=None, slab_off=0, own_stats=True):
+            f = dict(C=C_, acc=_r(self.acc[acc]), count=float(count), scale=self.bnt(name, 'scale', C_),
+                     dgamma=self.PG(name + '.weight'), dbeta=self.PG(name + '.bias'), mode=mode,
+                     coefA=None, coefB=None, coefC=None, corr1=None, corr2=None, mean=None, rstd=None)
+            if mode == 0:
+                f.update(mean=self.bnt(name, 'mean', C_), rstd=self.bnt(name, 'rstd', C_),
+                         coefA=_r(self.coef, 0), coefB=_r(self.coef, C_), coefC=_r(self.coef, 2 * C_))
+            else:
+                f.update(corr1=_r(slab.corr, slab_off), corr2=_r(slab.corr, slab.C + slab_off))
+            ops.op('bn_bwd_finalize', **f)
+
+        def bn_apply(C_, M_, dr, y, dy, colsum=None):
+            ops.op('bn_bwd_apply', M=M_, C=C_, dr=_r(dr), lddr=C_, y=_r(y), ldy=C_, coefA=_r(self.coef, 0),
+                   coefB=_r(self.coef, C_), coefC=_r(self.coef, 2 * C_), dy=_r(dy), lddy=C_, colsum=colsum)
+
+        dz, dr, dy1 = self.tmp_a, self.tmp_b, self.tmp_c
+
+        # ---- classifier
+        zero(A.corr)
+        mask_cls = _r(self.dropmask, 5 * sp.d1)
+        WG(n_img=B, H=H, W=W, cin=sp.C_aspp, cout=S.CLS_PAD, taps=1, dil=1, x=_r(A.x), ldx=A.C, in_mask=mask_cls,
+           in_mask_ld=self.drop_ld, dz=_r(self.dlogits16), lddz=S.CLS_PAD, dw=self.PG('classification.1.weight'))
+        C(n_img=B, H=H, W=W, cin=S.CLS_PAD, cout=sp.C_aspp, taps=1, dil=1, x=_r(self.dlogits16), ldx=S.CLS_PAD,
+          w=self.WT16('classification.1.weight'), out_mask=mask_cls, out_mask_ld=self.drop_ld, g=_r(A.g), ldg=A.C,
+          g_accumulate=0)
+
+        # ---- ASPP branches, last to first
+        for i in reversed(range(len(sp.aspp))):
+            a = sp.aspp[i]
+            y1 = self.y1[a.prefix]
+            n2 = a.prefix + '.norm2'
+            slab_extract(A, a.off_out, a.d1, dz, hw=H * W, mask=_r(self.dropmask, i * sp.d1), mask_ld=self.drop_ld,
+                         colsum=self.PG(a.prefix + '.conv2.bias'))
+            WG(n_img=B, H=H, W=W, cin=a.d0, cout=a.d1, taps=9, dil=a.rate, x=_r(y1), ldx=a.d0,
+               in_scale=self.bnt(n2, 'scale', a.d0), in_shift=self.bnt(n2, 'shift', a.d0), in_relu=1, dz=_r(dz),
+               lddz=a.d1, dw=self.PG(a.prefix + '.conv2.weight'))
+            C(n_img=B, H=H, W=W, cin=a.d1, cout=a.d0, taps=9, dil=a.rate, x=_r(dz), ldx=a.d1,
+              w=self.WT16(a.prefix + '.conv2.weight'), y=_r(dr), ldy=a.d0, epi_relu=1, ref=_r(y1), ldref=a.d0,
+              e_scale=self.bnt(n2, 'scale', a.d0), e_shift=self.bnt(n2, 'shift', a.d0),
+              e_mean=self.bnt(n2, 'mean', a.d0), e_rstd=self.bnt(n2, 'rstd', a.d0), s_acc=_r(self.acc[a.prefix + '.s2']))
+            bn_bwd(n2, a.d0, a.prefix + '.s2', M, 0)
+            bn_apply(a.d0, M, dr, y1, dy1, colsum=self.PG(a.prefix + '.conv1.bias'))
+            if a.bn_start:
+                n1 = a.prefix + '.norm1'
+                WG(n_img=B, H=H, W=W, cin=a.cin, cout=a.d0, taps=1, dil=1, x=_r(A.x, a.off_in), ldx=A.C,
+                   in_scale=self.bnt(n1, 'scale', a.cin), in_shift=self.bnt(n1, 'shift', a.cin), in_relu=1,
+                   dz=_r(dy1), lddz=a.d0, dw=self.PG(a.prefix + '.conv1.weight'))
+                C(n_img=B, H=H, W=W, cin=a.d0, cout=a.cin, taps=1, dil=1, x=_r(dy1), ldx=a.d0,
+                  w=self.WT16(a.prefix + '.conv1.weight'), epi_relu=1, ref=_r(A.x, a.off_in), ldref=A.C,
+                  e_scale=self.bnt(n1, 'scale', a.cin), e_shift=self.bnt(n1, 'shift', a.cin),
+                  e_mean=_r(A.mean, a.off_in), e_rstd=_r(A.rstd, a.off_in), s_acc=_r(self.acc[a.prefix + '.s1']),
+                  g=_r(A.g, a.off_in), ldg=A.C, g_accumulate=1)
+                bn_bwd(n1, a.cin, a.prefix + '.s1', M, 1, slab=A, slab_off=a.off_in)
+            else:
+                WG(n_img=B, H=H, W=W, cin=a.cin, cout=a.d0, taps=1, dil=1, x=_r(A.x, a.off_in), ldx=A.C, dz=_r(dy1),
+                   lddz=a.d0, dw=self.PG(a.prefix + '.conv1.weight'))
+                C(n_img=B, H=H, W=W, cin=a.d0, cout=a.cin, taps=1, dil=1, x=_r(dy1), ldx=a.d0,
+                  w=self.WT16(a.prefix + '.conv1.weight'), epi_relu=1, ref=_r(A.x, a.off_in), ldref=A.C,
+                  g=_r(A.g, a.off_in), ldg=A.C, g_accumulate=1)
+
+        # ---- ReLU + norm5
+        cf = sp.c_feat
+        n5 = 'features.norm5'
+        slab_extract(A, sp.off_feat, cf, dr, relu=1, yref=_r(self.t4out), ldyref=cf, r_scale=self.bnt(n5, 'scale', cf),
+                     r_shift=self.bnt(n5, 'shift', cf), r_mean=self.bnt(n5, 'mean', cf), r_rstd=self.bnt(n5, 'rstd', cf),
+                     s_acc=_r(self.acc['features.norm5.s']))
+        bn_bwd(n5, cf, 'features.norm5.s', M, 0)
+        bn_apply(cf, M, dr, self.t4out, dz)
+        dz_cur = dz            # gradient w.r.t. the output of the last transition conv, [M2][cout]
+
+        # ---- transitions and dense blocks, last to first
+        for bi in reversed(range(len(sp.blocks))):
+            blk = sp.blocks[bi]
+            slab = self.slabs[bi]
+            M, H, W = slab.M, slab.H, slab.W
+            nt = blk.trans_prefix + '.norm'
+            if bi + 1 < len(sp.blocks):
+                nxt = self.slabs[bi + 1]
+                if blk.pool_after:
+                    slab_extract(nxt, 0, blk.cout, dr)
+                    ops.op('avgpool_bwd', n_img=B, H=H, W=W, C=blk.cout, x=_r(dz), ldx=blk.cout, y=_r(dr),
+                           ldy=blk.cout, stat_acc=None)
+                else:
+                    slab_extract(nxt, 0, blk.cout, dz)
+                dz_cur = dz
+            zero(slab.corr)
+            WG(n_img=B, H=H, W=W, cin=blk.C, cout=blk.cout, taps=1, dil=1, x=_r(slab.x), ldx=slab.C,
+               in_scale=self.bnt(nt, 'scale', blk.C), in_shift=self.bnt(nt, 'shift', blk.C), in_relu=1, dz=_r(dz_cur),
+               lddz=blk.cout, dw=self.PG(blk.trans_prefix + '.conv.weight'))
+            C(n_img=B, H=H, W=W, cin=blk.cout, cout=blk.C, taps=1, dil=1, x=_r(dz_cur), ldx=blk.cout,
+              w=self.WT16(blk.trans_prefix + '.conv.weight'), epi_relu=1, ref=_r(slab.x), ldref=slab.C,
+              e_scale=self.bnt(nt, 'scale', blk.C), e_shift=self.bnt(nt, 'shift', blk.C), e_mean=_r(slab.mean),
+              e_rstd=_r(slab.rstd), s_acc=_r(self.acc[blk.trans_prefix + '.s']), g=_r(slab.g), ldg=slab.C,
+              g_accumulate=0)
+            bn_bwd(nt, blk.C, blk.trans_prefix + '.s', M, 1, slab=slab, slab_off=0)
+            for l in reversed(blk.layers):
+                n1, n2 = l.prefix + '.norm1', l.prefix + '.norm2'
+                y1 = self.y1[l.prefix]
+                slab_extract(slab, l.cin, l.growth, dz)
+                WG(n_img=B, H=H, W=W, cin=l.mid, cout=l.growth, taps=9, dil=l.dil, x=_r(y1), ldx=l.mid,
+                   in_scale=self.bnt(n2, 'scale', l.mid), in_shift=self.bnt(n2, 'shift', l.mid), in_relu=1, dz=_r(dz),
+                   lddz=l.growth, dw=self.PG(l.prefix + '.conv2.weight'))
+                C(n_img=B, H=H, W=W, cin=l.growth, cout=l.mid, taps=9, dil=l.dil, x=_r(dz), ldx=l.growth,
+                  w=self.WT16(l.prefix + '.conv2.weight'), y=_r(dr), ldy=l.mid, epi_relu=1, ref=_r(y1), ldref=l.mid,
+                  e_scale=self.bnt(n2, 'scale', l.mid), e_shift=self.bnt(n2, 'shift', l.mid),
+                  e_mean=self.bnt(n2, 'mean', l.mid), e_rstd=self.bnt(n2, 'rstd', l.mid),
+                  s_acc=_r(self.acc[l.prefix + '.s2']))
+                bn_bwd(n2, l.mid, l.prefix + '.s2', M, 0)
+                bn_apply(l.mid, M, dr, y1, dy1)
+                WG(n_img=B, H=H, W=W, cin=l.cin, cout=l.mid, taps=1, dil=1, x=_r(slab.x), ldx=slab.C,
+                   in_scale=self.bnt(n1, 'scale', l.cin), in_shift=self.bnt(n1, 'shift', l.cin), in_relu=1, dz=_r(dy1),
+                   lddz=l.mid, dw=self.PG(l.prefix + '.conv1.weight'))
+                C(n_img=B, H=H, W=W, cin=l.mid, cout=l.cin, taps=1, dil=1, x=_r(dy1), ldx=l.mid,
+                  w=self.WT16(l.prefix + '.conv1.weight'), epi_relu=1, ref=_r(slab.x), ldref=slab.C,
+                  e_scale=self.bnt(n1, 'scale', l.cin), e_shift=self.bnt(n1, 'shift', l.cin), e_mean=_r(slab.mean),
+                  e_rstd=_r(slab.rstd), s_acc=_r(self.acc[l.prefix + '.s1']), g=_r(slab.g), ldg=slab.C, g_accumulate=1)
+                bn_bwd(n1, l.cin, l.prefix + '.s1', M, 1, slab=slab, slab_off=0)
+
+        # ---- stem: maxpool + ReLU + norm0 backward, conv0 weight gradient
+        cs = sp.c_stem
+        s1 = self.slabs[0]
+        n0 = 'features.norm0'
+        slab_extract(s1, 0, cs, dz)
+        ops.op('maxpool_bwd', n_img=B, H=self.H0, W=self.W0, C=cs, x=_r(self.c0out), ldx=cs,
+               scale=self.bnt(n0, 'scale', cs), shift=self.bnt(n0, 'shift', cs), y=None, ldy=0, argmax=_r(self.argmax0),
+               stat_acc=None, dy=_r(dz), lddy=cs, dr=_r(dr), lddr=cs, mean=self.bnt(n0, 'mean', cs),
+               rstd=self.bnt(n0, 'rstd', cs), s_acc=_r(self.acc['features.norm0']))
+        bn_bwd(n0, cs, 'features.norm0', self.M0, 0)
+        bn_apply(cs, self.M0, dr, self.c0out, dy1)
+        zero(self.dw0pad)
+        WG(n_img=B, H=self.H0, W=self.W0, cin=S.STEM_KPAD, cout=cs, taps=1, dil=1, x=_r(self.col), ldx=S.STEM_KPAD,
+           dz=_r(dy1), lddz=cs, dw=_r(self.dw0pad))
+        ops.op('copy2d', src=_r(self.dw0pad), dst=self.PG('features.conv0.weight'), n=0, value=0, lds=S.STEM_KPAD,
+               ldd=S.STEM_K, rows=cs, cols=S.STEM_K, dst_cols=S.STEM_K, accumulate=1)
+        return ops
+
+    # ------------------------------------------------------------------ full-resolution logits API
+    def build_up_fwd(self):
+        sp = self.spec
+        if self.out_logits is None:
+            self.out_logits = self._zeros(self.B * sp.n_class * self.H * self.W)
+        ops = OpList()
+        ops.op('up_fwd', n_img=self.B, h=self.H2, w=self.W2, n_class=sp.n_class, ldl=S.CLS_PAD, logits=_r(self.logits),
+               out=_r(self.out_logits), argmax=None)
+        return ops
+
+    def build_argmax(self):
+        sp = self.spec
+        if self.out_argmax is None:
+            self.out_argmax = torch.zeros(self.B * self.H * self.W, dtype=torch.int64, device=self.device)
+        ops = OpList()
+        ops.op('up_argmax', n_img=self.B, h=self.H2, w=self.W2, n_class=sp.n_class, ldl=S.CLS_PAD,
+               logits=_r(self.logits), out=None, argmax=_r(self.out_argmax))
+        return ops
+
+    def build_up_bwd(self):
+        """dlogits (fp32 low-res, then bf16 copy) from the full-resolution NCHW fp32 gradient in self.grad_full."""
+        sp = self.spec
+        self.grad_full = self._zeros(self.B * sp.n_class * self.H * self.W)
+        self.accum_one = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float32, device=self.device)
+        ops = OpList()
+        ops.op('memset', src=None, dst=_r(self.dlogits), n=self.dlogits.numel() * 4, value=0, lds=0, ldd=0, rows=0,
+               cols=0, dst_cols=0, accumulate=0)
+        ops.op('up_bwd', n_img=self.B, h=self.H2, w=self.W2, n_class=sp.n_class, ldl=S.CLS_PAD, logits=_r(self.dlogits),
+               out=_r(self.grad_full), argmax=None)
+        # bf16 copy of the low-res gradient + classifier bias gradient: ce_finalize with the count pinned to 1
+        ops.op('ce_finalize', n_img=self.B, h=self.H2, w=self.W2, n_class=sp.n_class, ldl=S.CLS_PAD, logits=None,
+               labels=None, ignore_index=-1, dlogits=_r(self.dlogits), accum=_r(self.accum_one), grad_scale=1.0,
+               loss=None, dlogits_bf16=_r(self.dlogits16), lddb=S.CLS_PAD, dbias=self.PG('classification.1.bias'))
+        return ops
+
+    # ------------------------------------------------------------------ running
+    def programs(self):
+        be = self.backend
+        if self._fwd is None:
+            self._fwd = be.compile(self.build_forward())
+            if self.training:
+                self._fwd_loss = be.compile(self.build_loss())
+                self._loss_ignore = 255
+                self._bwd = be.compile(self.build_backward())
+        return self
+
+    def prog_up_fwd(self):
+        if self._up_fwd is None:
+            self._up_fwd = self.backend.compile(self.build_up_fwd())
+        return self._up_fwd
+
+    def prog_up_bwd(self):
+        if self._up_bwd is None:
+            self._up_bwd = self.backend.compile(self.build_up_bwd())
+        return self._up_bwd
+
+    def prog_argmax(self):
+        if self._argmax is None:
+            self._argmax = self.backend.compile(self.build_argmax())
+        return self._argmax
+
+    def set_input(self, x):
+        self.x_in.view(x.shape).copy_(x)
+
+    def set_labels(self, labels):
+        self.labels.view(labels.shape).copy_(labels)
+
+    def draw_dropout(self, generator=None, masks=None):
+        """Fill the per-(image, channel) Dropout2d scale tables (training only)."""
+        sp = self.spec
+        dm = self.dropmask.view(self.B, self.drop_ld)
+        if masks is not None:
+            for i, a in enumerate(sp.aspp):
+                dm[:, i * sp.d1:(i + 1) * sp.d1] = masks[a.prefix].to(dm)
+            dm[:, 5 * sp.d1:] = self._cls_mask_to_slab(masks['classification'].to(dm))
+            return
+        p0, p1 = sp.dropout0, sp.dropout1
+        u = torch.rand(dm.shape, device=dm.device, generator=generator)
+        n0 = 5 * sp.d1
+        dm[:, :n0] = (u[:, :n0] >= p0).to(dm.dtype) / (1.0 - p0) if p0 > 0 else 1.0
+        dm[:, n0:] = (u[:, n0:] >= p1).to(dm.dtype) / (1.0 - p1) if p1 > 0 else 1.0
+
+    def _cls_mask_to_slab(self, m):
+        # the classifier's input channel order IS the slab order ([ASPP_24 | ... | ASPP_3 | feature])
+        return m
