@@ -202,15 +202,18 @@ typedef struct dsaspp_gradx_desc {
     const void* yref; int32_t ldyref;
     const float* r_scale; const float* r_shift; const float* r_mean; const float* r_rstd;
     void* dz; int32_t lddz;
+    int32_t dz_f32;           /* store dz as fp32 (when it feeds a BatchNorm backward: see bn_bwd_apply) */
     float* s_acc;
     float* colsum;
 } dsaspp_gradx_desc;
 int dsaspp_grad_extract(const dsaspp_gradx_desc* d, dsaspp_stream_t stream);
 
-/* dy = A[c]*dr + B[c]*y + Cc[c] -> bf16 ; colsum[c] += dy when non-NULL */
+/* dy = A[c]*dr + B[c]*y + Cc[c] -> bf16 ; colsum[c] += dy when non-NULL.
+ * dr is normally fp32 (dr_f32): the BatchNorm backward removes the mean and xhat components of
+ * dr, which can dominate it, so rounding dr to bf16 first would swamp what is left. */
 typedef struct dsaspp_bnapply_desc {
     int64_t M; int32_t C;
-    const void* dr; int32_t lddr;
+    const void* dr; int32_t lddr; int32_t dr_f32;
     const void* y; int32_t ldy;
     const float* coefA; const float* coefB; const float* coefC;
     void* dy; int32_t lddy;
@@ -248,7 +251,8 @@ typedef struct dsaspp_maxpool_desc {
     float* stat_acc;
     /* backward only */
     const void* dy; int32_t lddy;     /* bf16 gradient w.r.t. pooled output */
-    void* dr; int32_t lddr;           /* bf16 masked gradient w.r.t. norm0 output */
+    void* dr; int32_t lddr;           /* masked gradient w.r.t. norm0 output (bf16, or fp32 if dr_f32) */
+    int32_t dr_f32;
     const float* mean; const float* rstd;
     float* s_acc;
 } dsaspp_maxpool_desc;

@@ -67,13 +67,14 @@ class HipBackend:
         _lib.check(getattr(self.lib, entry)(ctypes.byref(d), ctypes.c_void_p(stream)))
 
     # ------------------------------------------------------------------ weight shadows
-    def refresh_weights(self, model):
+    def refresh_weights(self, model, cast=True):
         """fp32 arena -> bf16 shadow (same offsets), padded stem rows, transposed copies for the dgrad convs."""
         from . import spec as S
         lib = self.lib
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         ar = model.arena
-        _lib.check(lib.dsaspp_cast_bf16(model._flat.data_ptr(), model._w16.data_ptr(), ar.size, stream))
+        if cast:
+            _lib.check(lib.dsaspp_cast_bf16(model._flat.data_ptr(), model._w16.data_ptr(), ar.size, stream))
         e0 = ar.by_name['features.conv0.weight']
         _lib.check(lib.dsaspp_copy2d_f32_bf16(model._flat.data_ptr() + 4 * e0.off, S.STEM_K, model._w0_16.data_ptr(),
                                               S.STEM_KPAD, e0.rows, S.STEM_K, S.STEM_KPAD, stream))

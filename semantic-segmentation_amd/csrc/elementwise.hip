@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void grad_extract_kernel(const dsaspp_gradx_de
                     if (!(pre > 0.f)) v[e] = 0.f;
                 }
             }
-            *reinterpret_cast<uint4*>(dz + m * d.lddz + c) = pack8(v);
+            if (d.dz_f32) store8f(reinterpret_cast<float*>(d.dz) + m * d.lddz + c, v);
+            else *reinterpret_cast<uint4*>(dz + m * d.lddz + c) = pack8(v);
             if (d.s_acc) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { part[0][e] += v[e]; part[1][e] += v[e] * ((y[e] - rm[e]) * rr[e]); }
@@ -201,7 +202,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const dsaspp_bnapply_desc
     if (act) {
         for (int64_t m = (int64_t)blockIdx.y * RB + ry; m < d.M; m += (int64_t)gridDim.y * RB) {
             float a[8], y[8], o[8];
-            unpack8(*reinterpret_cast<const uint4*>(dr + m * d.lddr + c), a);
+            if (d.dr_f32) load8f(reinterpret_cast<const float*>(d.dr) + m * d.lddr + c, a);
+            else unpack8(*reinterpret_cast<const uint4*>(dr + m * d.lddr + c), a);
             unpack8(*reinterpret_cast<const uint4*>(yy + m * d.ldy + c), y);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { o[e] = fmaf(A[e], a[e], fmaf(B[e], y[e], Cc[e])); part[0][e] += o[e]; }
@@ -419,7 +421,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const dsaspp_maxpool_d
                 part[0][e] += g[e];
                 part[1][e] += g[e] * ((x[e] - mu[e]) * rs[e]);
             }
-            *reinterpret_cast<uint4*>(drg + m * d.lddr + c) = pack8(g);
+            if (d.dr_f32) store8f(reinterpret_cast<float*>(d.dr) + m * d.lddr + c, g);
+            else *reinterpret_cast<uint4*>(drg + m * d.lddr + c) = pack8(g);
         }
     }
     if (d.s_acc) block_colsum<CGB, 2>(part, red, d.s_acc, d.C, blockIdx.x * CGB, 2 * d.C, blockIdx.y % DS_R);

@@ -207,7 +207,7 @@ def op_grad_extract(f):
     if f['relu']:
         pre = y * _vec(f['r_scale'], C) + _vec(f['r_shift'], C) if f['r_scale'] is not None else y
         v = torch.where(pre > 0, v, torch.zeros_like(v))
-    _view(f['dz'], M, C, f['lddz']).copy_(v.to(bf16))
+    _view(f['dz'], M, C, f['lddz']).copy_(v if f['dz_f32'] else v.to(bf16))
     if f['s_acc'] is not None:
         xh = (y - _vec(f['r_mean'], C)) * _vec(f['r_rstd'], C)
         acc = _view(f['s_acc'], R, 2 * C, 2 * C)
@@ -295,7 +295,7 @@ def op_maxpool_bwd(f):
     g = g.view(n * H * W, C)
     pre = x * _vec(f['scale'], C) + _vec(f['shift'], C)
     g = torch.where(pre > 0, g, torch.zeros_like(g))
-    _view(f['dr'], n * H * W, C, f['lddr']).copy_(g.to(bf16))
+    _view(f['dr'], n * H * W, C, f['lddr']).copy_(g if f['dr_f32'] else g.to(bf16))
     if f['s_acc'] is not None:
         xh = (x - _vec(f['mean'], C)) * _vec(f['rstd'], C)
         acc = _view(f['s_acc'], R, 2 * C, 2 * C)
@@ -419,7 +419,7 @@ class ModelBackend:
     def call(self, kind, stream=None, **fields):
         ModelProgram([(kind, fields)]).run()
 
-    def refresh_weights(self, model):
+    def refresh_weights(self, model, cast=True):
         ar = model.arena
         model._w16.copy_(model._flat.to(bf16))
         e0 = ar.by_name['features.conv0.weight']

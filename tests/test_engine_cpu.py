@@ -1,0 +1,112 @@
+"""CPU tests (no GPU): the Engine's orchestration run through the CPU kernel model against the oracle.
+
+With fp32 activation storage the descriptor program must reproduce the oracle's loss, every parameter
+gradient and the BatchNorm running statistics to fp32 accuracy -- this pins the slab layout, the
+"concatenate in front" ASPP ordering and the single-pass BatchNorm-backward correction scheme.
+With bf16 storage (what the HIP kernels do) the logits must stay within the 2e-2 budget.
+"""
+import pytest
+import torch
+
+import kernel_model
+from e2e_common import TINY_CFG, grad_report, make_batch, make_dropout_masks, make_pair, oracle_train
+
+
+@pytest.fixture
+def fp32_model():
+    kernel_model.set_act_dtype(torch.float32)
+    yield
+    kernel_model.set_act_dtype(torch.bfloat16)
+
+
+def test_eval_forward_fp32(fp32_model):
+    ref, mod = make_pair(TINY_CFG)
+    mod.set_backend(kernel_model.ModelBackend())
+    x, _ = make_batch(2, 64, 96)
+    ref.eval(); mod.eval()
+    with torch.no_grad():
+        yr, ym = ref(x), mod(x)
+    assert ym.shape == yr.shape == (2, 19, 64, 96)
+    assert float((yr - ym).abs().max() / yr.abs().max()) < 1e-4      # fp32 tolerance of the north star
+    am = mod.predict(x)
+    assert float((am == yr.argmax(1)).float().mean()) > 0.999
+
+
+def test_train_step_fp32(fp32_model):
+    ref, mod = make_pair(TINY_CFG)
+    mod.set_backend(kernel_model.ModelBackend())
+    x, labels = make_batch(2, 64, 96)
+    masks = make_dropout_masks(ref, 2, torch.Generator().manual_seed(5))
+    loss_r, g_ref = oracle_train(ref, x, labels, masks)
+    mod.train()
+    loss_m = mod.train_step(x, labels, dropout_masks=masks)
+    assert abs(float(loss_r) - float(loss_m)) < 1e-5
+    rel, cos, worst = grad_report(g_ref, {n: p.grad for n, p in mod.named_parameters()})
+    assert rel < 1e-3 and cos > 0.99999, (rel, cos, worst)
+    br = dict(ref.named_buffers())
+    for n, b in mod.named_buffers():
+        assert float((br[n].float() - b.float()).abs().max()) < 1e-4, n
+
+
+def test_autograd_path_matches_fused_path(fp32_model):
+    """model(x) -> CrossEntropyLoss -> backward (the reference's loop, graph_seg_main.py:237-239)."""
+    ref, mod = make_pair(TINY_CFG)
+    mod.set_backend(kernel_model.ModelBackend())
+    x, labels = make_batch(1, 64, 64)
+    mod.train()
+    masks = make_dropout_masks(ref, 1, torch.Generator().manual_seed(5))
+    loss_r, g_ref = oracle_train(ref, x, labels, masks)
+    eng = mod.engine(1, 64, 64, True)
+    orig = eng.draw_dropout
+    eng.draw_dropout = lambda generator=None, masks=None: orig(masks=masks if masks is not None else _masks)
+    _masks = masks
+    out = mod(x)
+    assert out.requires_grad
+    loss = torch.nn.CrossEntropyLoss(ignore_index=255)(out, labels)
+    loss.backward()
+    assert abs(float(loss) - float(loss_r)) < 1e-5
+    rel, cos, worst = grad_report(g_ref, {n: p.grad for n, p in mod.named_parameters()})
+    assert rel < 1e-3, (rel, cos, worst)
+
+
+def test_bf16_storage_budget():
+    ref, mod = make_pair(TINY_CFG)
+    mod.set_backend(kernel_model.ModelBackend())
+    x, _ = make_batch(2, 64, 96)
+    ref.eval(); mod.eval()
+    with torch.no_grad():
+        yr, ym = ref(x), mod(x)
+    assert float((yr - ym).abs().max() / yr.abs().max()) < 2e-2
+
+
+def test_state_dict_compat():
+    ref, mod = make_pair(TINY_CFG)
+    sd_r, sd_m = ref.state_dict(), mod.state_dict()
+    assert list(sd_r.keys()) == list(sd_m.keys())
+    for k in sd_r:
+        assert sd_r[k].shape == sd_m[k].shape and torch.equal(sd_r[k], sd_m[k]), k
+    # DataParallel-style and legacy dotted keys load too
+    legacy = {}
+    for k, v in sd_r.items():
+        k2 = 'module.' + k.replace('.norm1.', '.norm.1.').replace('.conv2.', '.conv.2.')
+        legacy[k2] = v
+    import denseASPP
+    m2 = denseASPP.DenseASPP(TINY_CFG)
+    m2.load_state_dict(legacy)
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, sd_r[k]), k
+    wrapped = torch.nn.DataParallel(mod)
+    assert all(k.startswith('module.') for k in wrapped.state_dict())
+    wrapped.load_state_dict(wrapped.state_dict())
+
+
+def test_ctor_forms():
+    import denseASPP
+    a = denseASPP.DenseASPP(TINY_CFG, 19, 8)
+    b = denseASPP.DenseASPP(object(), model_cfg=TINY_CFG)
+    c = denseASPP.DenseASPP(TINY_CFG, n_class=7)
+    assert a.spec.n_class == b.spec.n_class == 19 and c.spec.n_class == 7
+    with pytest.raises(NotImplementedError):
+        denseASPP.DenseASPP(TINY_CFG, output_stride=16)
+    with pytest.raises(TypeError):
+        denseASPP.DenseASPP()

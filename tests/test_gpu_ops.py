@@ -1,0 +1,263 @@
+"""-m gpu: every HIP kernel against the CPU kernel model on the same seeded inputs, through the C ABI."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from optools import Ref, bf, close, run_both  # noqa: E402
+
+R = 16
+
+
+def conv_fields(n, H, W, cin, cout, taps, dil, ldx=None, ldy=None, scale=True, relu=True, in_mask=False, bias=False,
+                out_mask=False, y_f32=False, stats=False, epi_relu=False, e_scale=False, s_acc=False, g=False,
+                g_acc=False, xoff=0, yoff=0, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    M = n * H * W
+    ldx = ldx or cin
+    ldy = ldy or cout
+    x = bf(torch.randn(M * ldx + xoff, generator=gen))
+    w = bf(torch.randn(cout * taps * cin, generator=gen) * (taps * cin) ** -0.5)
+    f = dict(n_img=n, H=H, W=W, cin=cin, cout=cout, taps=taps, dil=dil, x=Ref(x, xoff), ldx=ldx, w=Ref(w),
+             in_scale=None, in_shift=None, in_relu=int(relu), in_mask=None, in_mask_ld=0, bias=None, out_mask=None,
+             out_mask_ld=0, y=None, ldy=ldy, y_f32=int(y_f32), stat_acc=None, epi_relu=int(epi_relu), ref=None, ldref=0,
+             e_scale=None, e_shift=None, e_mean=None, e_rstd=None, s_acc=None, g=None, ldg=0, g_accumulate=int(g_acc))
+    if scale:
+        f['in_scale'] = Ref(torch.rand(cin, generator=gen) + 0.5)
+        f['in_shift'] = Ref(torch.randn(cin, generator=gen) * 0.3)
+    if in_mask:
+        f['in_mask'] = Ref((torch.rand(n * cin, generator=gen) > 0.2).float() / 0.8)
+        f['in_mask_ld'] = cin
+    if bias:
+        f['bias'] = Ref(torch.randn(cout, generator=gen))
+    if out_mask:
+        f['out_mask'] = Ref((torch.rand(n * cout, generator=gen) > 0.2).float() / 0.8)
+        f['out_mask_ld'] = cout
+    if epi_relu or s_acc:
+        f['ref'] = Ref(bf(torch.randn(M * ldy, generator=gen)))
+        f['ldref'] = ldy
+    if e_scale:
+        f['e_scale'] = Ref(torch.rand(cout, generator=gen) + 0.5)
+        f['e_shift'] = Ref(torch.randn(cout, generator=gen) * 0.3)
+    if s_acc:
+        f['e_mean'] = Ref(torch.randn(cout, generator=gen) * 0.1)
+        f['e_rstd'] = Ref(torch.rand(cout, generator=gen) + 0.5)
+        f['s_acc'] = Ref(torch.zeros(R * 2 * cout))
+    if g:
+        f['g'] = Ref(torch.randn(M * ldy + yoff, generator=gen), yoff)
+        f['ldg'] = ldy
+    else:
+        f['y'] = Ref(torch.zeros(M * ldy + yoff, dtype=torch.float32 if y_f32 else torch.bfloat16), yoff)
+    if stats:
+        f['stat_acc'] = Ref(torch.zeros(R * 2 * cout))
+    return f
+
+
+def check_conv(f, tol=2e-2):
+    out = run_both('conv', f)
+    for k in ('y', 'g'):
+        if k in out:
+            close(out[k][0], out[k][1], tol, 'conv.' + k)
+    for k in ('stat_acc', 's_acc'):
+        if k in out:
+            c, g = out[k]
+            cout = f['cout']
+            close(c.view(R, -1).sum(0), g.view(R, -1).sum(0), 2e-2, 'conv.' + k)
+
+
+CONV_CASES = [
+    dict(n=2, H=9, W=13, cin=144, cout=192, taps=1, dil=1, ldx=160, stats=True),
+    dict(n=1, H=16, W=24, cin=192, cout=48, taps=9, dil=2, ldy=96, yoff=48, stats=True),
+    dict(n=2, H=12, W=20, cin=64, cout=128, taps=9, dil=6, bias=True, out_mask=True, stats=True),
+    dict(n=2, H=8, W=16, cin=176, cout=32, taps=1, dil=1, scale=False, relu=False, in_mask=True, bias=True, y_f32=True),
+    dict(n=1, H=24, W=16, cin=48, cout=192, taps=9, dil=4, scale=False, relu=False, y_f32=True, epi_relu=True,
+         e_scale=True, s_acc=True),
+    dict(n=2, H=10, W=12, cin=192, cout=336, taps=1, dil=1, scale=False, relu=False, epi_relu=True, e_scale=True,
+         s_acc=True, g=True, g_acc=True, ldy=400, yoff=8),
+    dict(n=1, H=8, W=16, cin=32, cout=256, taps=1, dil=1, scale=False, relu=False, out_mask=True, g=True),
+    dict(n=1, H=16, W=16, cin=128, cout=64, taps=9, dil=24),
+    dict(n=1, H=8, W=8, cin=160, cout=16, taps=1, dil=1, scale=False, relu=False, stats=True),
+    dict(n=3, H=8, W=16, cin=256, cout=40, taps=9, dil=1, stats=True),
+]
+
+
+@pytest.mark.parametrize('case', range(len(CONV_CASES)))
+def test_conv(case):
+    check_conv(conv_fields(seed=case, **CONV_CASES[case]))
+
+
+def wgrad_fields(n, H, W, cin, cout, taps, dil, ldx=None, lddz=None, scale=True, relu=True, in_mask=False, seed=0,
+                 ksplit=0):
+    gen = torch.Generator().manual_seed(100 + seed)
+    M = n * H * W
+    ldx = ldx or cin
+    lddz = lddz or cout
+    f = dict(n_img=n, H=H, W=W, cin=cin, cout=cout, taps=taps, dil=dil, x=Ref(bf(torch.randn(M * ldx, generator=gen))),
+             ldx=ldx, in_scale=None, in_shift=None, in_relu=int(relu), in_mask=None, in_mask_ld=0,
+             dz=Ref(bf(torch.randn(M * lddz, generator=gen))), lddz=lddz, dw=Ref(torch.zeros(cout * taps * cin)),
+             ksplit=ksplit)
+    if scale:
+        f['in_scale'] = Ref(torch.rand(cin, generator=gen) + 0.5)
+        f['in_shift'] = Ref(torch.randn(cin, generator=gen) * 0.3)
+    if in_mask:
+        f['in_mask'] = Ref((torch.rand(n * cin, generator=gen) > 0.2).float() / 0.8)
+        f['in_mask_ld'] = cin
+    return f
+
+
+WGRAD_CASES = [
+    dict(n=2, H=9, W=13, cin=144, cout=192, taps=1, dil=1, ldx=160),
+    dict(n=1, H=16, W=24, cin=192, cout=48, taps=9, dil=2),
+    dict(n=2, H=8, W=16, cin=176, cout=32, taps=1, dil=1, scale=False, relu=False, in_mask=True),
+    dict(n=2, H=12, W=12, cin=64, cout=128, taps=9, dil=3, lddz=136),
+    dict(n=1, H=16, W=20, cin=160, cout=96, taps=1, dil=1, scale=False, relu=False),
+    dict(n=2, H=10, W=10, cin=200, cout=336, taps=1, dil=1, ksplit=3),
+]
+
+
+@pytest.mark.parametrize('case', range(len(WGRAD_CASES)))
+def test_wgrad(case):
+    f = wgrad_fields(seed=case, **WGRAD_CASES[case])
+    out = run_both('wgrad', f)
+    close(out['dw'][0], out['dw'][1], 5e-3, 'wgrad.dw')
+
+
+def test_bn_finalize_and_bwd():
+    gen = torch.Generator().manual_seed(3)
+    C, cn, c0 = 96, 40, 24
+    acc = torch.rand(R * 2 * cn, generator=gen) * 10
+    acc.view(R, 2 * cn)[:, cn:] += 100.0
+    f = dict(C=C, acc=Ref(acc), acc_c0=c0, acc_cn=cn, count=1000.0, mean=Ref(torch.randn(C, generator=gen)),
+             var=Ref(torch.rand(C, generator=gen) + 0.1), rstd=Ref(torch.ones(C)), gamma=Ref(torch.rand(C, generator=gen)),
+             beta=Ref(torch.randn(C, generator=gen)), running_mean=Ref(torch.zeros(C)), running_var=Ref(torch.ones(C)),
+             num_batches_tracked=Ref(torch.zeros(1, dtype=torch.int64)), momentum=0.1, eps=1e-5, use_running=0,
+             scale=Ref(torch.zeros(C)), shift=Ref(torch.zeros(C)))
+    out = run_both('bn_finalize', f)
+    for k, (c, g) in out.items():
+        close(c, g, 1e-5, 'bn_finalize.' + k)
+    f['use_running'] = 1
+    out = run_both('bn_finalize', f)
+    for k, (c, g) in out.items():
+        close(c, g, 1e-5, 'bn_finalize(eval).' + k)
+    for mode in (0, 1):
+        fb = dict(C=C, acc=Ref(torch.randn(R * 2 * C, generator=gen)), count=777.0, scale=Ref(torch.rand(C, generator=gen)),
+                  mean=Ref(torch.randn(C, generator=gen)), rstd=Ref(torch.rand(C, generator=gen) + 0.5),
+                  dgamma=Ref(torch.randn(C, generator=gen)), dbeta=Ref(torch.randn(C, generator=gen)), mode=mode,
+                  coefA=Ref(torch.zeros(C)), coefB=Ref(torch.zeros(C)), coefC=Ref(torch.zeros(C)),
+                  corr1=Ref(torch.randn(C, generator=gen)), corr2=Ref(torch.randn(C, generator=gen)))
+        out = run_both('bn_bwd_finalize', fb)
+        for k, (c, g) in out.items():
+            close(c, g, 1e-5, 'bn_bwd_finalize.' + k)
+
+
+@pytest.mark.parametrize('C', [48, 200])
+def test_rowwise(C):
+    gen = torch.Generator().manual_seed(C)
+    n, H, W = 2, 10, 12
+    M, hw = n * H * W, H * W
+    ld = C + 16
+    # bn_act
+    f = dict(M=M, C=C, x=Ref(bf(torch.randn(M * ld, generator=gen))), ldx=ld, scale=Ref(torch.rand(C, generator=gen) + 0.5),
+             shift=Ref(torch.randn(C, generator=gen) * 0.2), relu=1, y=Ref(torch.zeros(M * ld, dtype=torch.bfloat16)), ldy=ld,
+             stat_acc=Ref(torch.zeros(R * 2 * C)))
+    out = run_both('bn_act', f)
+    close(out['y'][0], out['y'][1], 1e-2, 'bn_act.y')
+    close(out['stat_acc'][0].view(R, -1).sum(0), out['stat_acc'][1].view(R, -1).sum(0), 1e-3, 'bn_act.stats')
+    # grad_extract, all options
+    for dz_f32 in (0, 1):
+        f = dict(M=M, C=C, hw=hw, g=Ref(torch.randn(M * ld, generator=gen)), ldg=ld, corr1=Ref(torch.randn(C, generator=gen) * 0.1),
+                 corr2=Ref(torch.randn(C, generator=gen) * 0.1), xs=Ref(bf(torch.randn(M * ld, generator=gen))), ldxs=ld,
+                 s_mean=Ref(torch.randn(C, generator=gen) * 0.1), s_rstd=Ref(torch.rand(C, generator=gen) + 0.5),
+                 mask=Ref((torch.rand(n * C, generator=gen) > 0.2).float() / 0.8), mask_ld=C, relu=1,
+                 yref=Ref(bf(torch.randn(M * ld, generator=gen))), ldyref=ld, r_scale=Ref(torch.rand(C, generator=gen) + 0.5),
+                 r_shift=Ref(torch.randn(C, generator=gen) * 0.2), r_mean=Ref(torch.randn(C, generator=gen) * 0.1),
+                 r_rstd=Ref(torch.rand(C, generator=gen) + 0.5),
+                 dz=Ref(torch.zeros(M * C, dtype=torch.float32 if dz_f32 else torch.bfloat16)), lddz=C, dz_f32=dz_f32,
+                 s_acc=Ref(torch.zeros(R * 2 * C)), colsum=None)
+        out = run_both('grad_extract', f)
+        close(out['dz'][0], out['dz'][1], 1e-2, 'grad_extract.dz')
+        close(out['s_acc'][0].view(R, -1).sum(0), out['s_acc'][1].view(R, -1).sum(0), 1e-3, 'grad_extract.s_acc')
+    f.update(s_acc=None, colsum=Ref(torch.zeros(C)), relu=0, yref=None, r_scale=None, r_shift=None, r_mean=None, r_rstd=None)
+    out = run_both('grad_extract', f)
+    close(out['colsum'][0], out['colsum'][1], 1e-3, 'grad_extract.colsum')
+    # bn_bwd_apply
+    for dr_f32 in (0, 1):
+        dr = torch.randn(M * C, generator=gen)
+        f = dict(M=M, C=C, dr=Ref(dr if dr_f32 else bf(dr)), lddr=C, dr_f32=dr_f32, y=Ref(bf(torch.randn(M * ld, generator=gen))),
+                 ldy=ld, coefA=Ref(torch.randn(C, generator=gen)), coefB=Ref(torch.randn(C, generator=gen)),
+                 coefC=Ref(torch.randn(C, generator=gen)), dy=Ref(torch.zeros(M * C, dtype=torch.bfloat16)), lddy=C,
+                 colsum=Ref(torch.zeros(C)))
+        out = run_both('bn_bwd_apply', f)
+        close(out['dy'][0], out['dy'][1], 1e-2, 'bn_bwd_apply.dy')
+        close(out['colsum'][0], out['colsum'][1], 1e-3, 'bn_bwd_apply.colsum')
+    # avgpool
+    f = dict(n_img=n, H=H, W=W, C=C, x=Ref(bf(torch.randn(M * ld, generator=gen))), ldx=ld,
+             y=Ref(torch.zeros(M // 4 * ld, dtype=torch.bfloat16)), ldy=ld, stat_acc=Ref(torch.zeros(R * 2 * C)))
+    out = run_both('avgpool_fwd', f)
+    close(out['y'][0], out['y'][1], 1e-2, 'avgpool_fwd.y')
+    close(out['stat_acc'][0].view(R, -1).sum(0), out['stat_acc'][1].view(R, -1).sum(0), 1e-3, 'avgpool_fwd.stats')
+    f = dict(n_img=n, H=H, W=W, C=C, x=Ref(torch.zeros(M * ld, dtype=torch.bfloat16)), ldx=ld,
+             y=Ref(bf(torch.randn(M // 4 * ld, generator=gen))), ldy=ld, stat_acc=None)
+    out = run_both('avgpool_bwd', f)
+    close(out['x'][0], out['x'][1], 1e-2, 'avgpool_bwd.x')
+
+
+def test_stem_ops():
+    gen = torch.Generator().manual_seed(11)
+    n, H, W, C = 2, 24, 40, 96
+    f = dict(n_img=n, H=H, W=W, x=Ref(torch.randn(n * 3 * H * W, generator=gen)),
+             col=Ref(torch.ones(n * (H // 2) * (W // 2) * 160, dtype=torch.bfloat16)), ldcol=160)
+    out = run_both('im2col', f)
+    assert torch.equal(out['col'][0].float(), out['col'][1].float())
+    Hc, Wc = H // 2, W // 2
+    Mi, Mo = n * Hc * Wc, n * (Hc // 2) * (Wc // 2)
+    x = bf(torch.randn(Mi * C, generator=gen))
+    f = dict(n_img=n, H=Hc, W=Wc, C=C, x=Ref(x), ldx=C, scale=Ref(torch.rand(C, generator=gen) + 0.5),
+             shift=Ref(torch.randn(C, generator=gen) * 0.2), y=Ref(torch.zeros(Mo * 128, dtype=torch.bfloat16)), ldy=128,
+             argmax=Ref(torch.zeros(Mo * C, dtype=torch.uint8)), stat_acc=Ref(torch.zeros(R * 2 * C)), dy=None, lddy=0,
+             dr=None, lddr=0, dr_f32=0, mean=None, rstd=None, s_acc=None)
+    out = run_both('maxpool_fwd', f)
+    close(out['y'][0], out['y'][1], 1e-2, 'maxpool_fwd.y')
+    assert torch.equal(out['argmax'][0], out['argmax'][1])
+    close(out['stat_acc'][0].view(R, -1).sum(0), out['stat_acc'][1].view(R, -1).sum(0), 1e-3, 'maxpool_fwd.stats')
+    f.update(y=None, stat_acc=None, argmax=Ref(out['argmax'][0].clone()), dy=Ref(bf(torch.randn(Mo * C, generator=gen))), lddy=C,
+             dr=Ref(torch.zeros(Mi * C)), lddr=C, dr_f32=1, mean=Ref(torch.randn(C, generator=gen) * 0.1),
+             rstd=Ref(torch.rand(C, generator=gen) + 0.5), s_acc=Ref(torch.zeros(R * 2 * C)))
+    out = run_both('maxpool_bwd', f)
+    close(out['dr'][0], out['dr'][1], 1e-3, 'maxpool_bwd.dr')
+    close(out['s_acc'][0].view(R, -1).sum(0), out['s_acc'][1].view(R, -1).sum(0), 1e-3, 'maxpool_bwd.s_acc')
+
+
+@pytest.mark.parametrize('shape', [(2, 4, 6), (1, 8, 16), (3, 5, 3)])
+def test_upsample_ce(shape):
+    n, h, w = shape
+    gen = torch.Generator().manual_seed(h * w)
+    nc, ldl = 19, 32
+    M = n * h * w
+    logits = torch.randn(M * ldl, generator=gen) * 2
+    labels = torch.randint(0, nc, (n * 64 * h * w,), generator=gen)
+    labels[torch.rand(labels.shape, generator=gen) < 0.1] = 255
+    f = dict(n_img=n, h=h, w=w, n_class=nc, ldl=ldl, logits=Ref(logits), labels=Ref(labels), ignore_index=255,
+             dlogits=Ref(torch.zeros(M * ldl)), accum=Ref(torch.zeros(4)), grad_scale=1.0, loss=Ref(torch.zeros(1)),
+             dlogits_bf16=Ref(torch.zeros(M * ldl, dtype=torch.bfloat16)), lddb=ldl, dbias=Ref(torch.zeros(32)))
+    out = run_both('upce', f)
+    close(out['accum'][0][:2], out['accum'][1][:2], 1e-4, 'upce.accum')
+    close(out['dlogits'][0], out['dlogits'][1], 1e-4, 'upce.dlogits')
+    out = run_both('ce_finalize', f)
+    close(out['loss'][0], out['loss'][1], 1e-4, 'ce_finalize.loss')
+    close(out['dlogits'][0], out['dlogits'][1], 1e-4, 'ce_finalize.dlogits')
+    close(out['dlogits_bf16'][0], out['dlogits_bf16'][1], 1e-2, 'ce_finalize.dlogits16')
+    close(out['dbias'][0], out['dbias'][1], 1e-3, 'ce_finalize.dbias')
+    # materialised upsample, its adjoint and the argmax variant
+    fu = dict(n_img=n, h=h, w=w, n_class=nc, ldl=ldl, logits=Ref(logits), out=Ref(torch.zeros(n * nc * 64 * h * w)), argmax=None)
+    out = run_both('up_fwd', fu)
+    close(out['out'][0], out['out'][1], 1e-5, 'up_fwd.out')
+    fa = dict(n_img=n, h=h, w=w, n_class=nc, ldl=ldl, logits=Ref(logits), out=None,
+              argmax=Ref(torch.zeros(n * 64 * h * w, dtype=torch.int64)))
+    out = run_both('up_argmax', fa)
+    agree = (out['argmax'][0] == out['argmax'][1]).float().mean().item()
+    assert agree >= 0.9999, agree
+    fb = dict(n_img=n, h=h, w=w, n_class=nc, ldl=ldl, logits=Ref(torch.zeros(M * ldl)),
+              out=Ref(torch.randn(n * nc * 64 * h * w, generator=gen)), argmax=None)
+    out = run_both('up_bwd', fb)
+    close(out['logits'][0], out['logits'][1], 1e-4, 'up_bwd.dlogits')
