@@ -16,6 +16,16 @@ def _logit_err(yr, ym):
     return float((yr - ym).abs().max() / yr.abs().max())
 
 
+def _argmax_agreement(yr, ym, tol=2e-2):
+    """Agreement of the arg-max labels, overall and on the pixels whose oracle top-1 margin exceeds the
+    error budget (2 * tol * max|logit|): a flip there would be an error, a flip elsewhere is a tie."""
+    top2 = yr.topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    clear = margin > 2 * tol * float(yr.abs().max())
+    same = ym.argmax(1) == yr.argmax(1)
+    return float(same.float().mean()), float(same[clear].float().mean()), float(clear.float().mean())
+
+
 def test_eval_forward_tiny():
     ref, mod = make_pair(TINY_CFG)
     x, _ = make_batch(2, 64, 96)
@@ -27,13 +37,18 @@ def test_eval_forward_tiny():
     assert ym.shape == yr.shape
     assert _logit_err(yr, ym) < 2e-2                      # bf16 budget of the north star
     am = mod.predict(x.cuda()).cpu()
-    agree = float((am == yr.argmax(1)).float().mean())
-    assert agree >= 0.99, agree                           # tiny random net: near-ties are common
+    assert torch.equal(am, ym.argmax(1))                  # fused upsample+argmax == argmax of the materialised logits
+    overall, clear, frac = _argmax_agreement(yr, ym)
+    assert clear >= 0.999 and overall >= 0.97, (overall, clear, frac)
 
 
 def test_eval_forward_densenet121_matches_oracle():
     from cfgs import DenseASPP121
     ref, mod = make_pair(DenseASPP121.Model_CFG, randomize_bn=False)
+    # a random-init classifier gives near-tied logits; widen the margins so arg-max agreement is meaningful
+    with torch.no_grad():
+        ref.classification[1].weight.mul_(8.0)
+    mod.load_state_dict(ref.state_dict())
     x, _ = make_batch(1, 128, 256)
     ref.eval()
     mod = mod.cuda().eval()
@@ -41,34 +56,69 @@ def test_eval_forward_densenet121_matches_oracle():
         yr = ref(x)
         ym = mod(x.cuda()).cpu()
     assert _logit_err(yr, ym) < 2e-2
-    agree = float((ym.argmax(1) == yr.argmax(1)).float().mean())
-    assert agree >= 0.999, agree
+    overall, clear, frac = _argmax_agreement(yr, ym)
+    assert clear >= 0.999, (overall, clear, frac)
+    assert overall >= 0.99, (overall, clear, frac)
 
 
-def test_train_step_tiny_vs_kernel_model_and_oracle():
+def _copy_engine_state(src, dst):
+    """Copy every forward-pass buffer of one Engine into another (same configuration, other device)."""
+    def cp(a, b):
+        b.copy_(a.to(b.device))
+    for sa, sb in zip(src.slabs + [src.aslab], dst.slabs + [dst.aslab]):
+        for k in ('x', 'mean', 'var', 'rstd'):
+            cp(getattr(sa, k), getattr(sb, k))
+    for k in src.y1:
+        cp(src.y1[k], dst.y1[k])
+    for k in src.bn:
+        cp(src.bn[k], dst.bn[k])
+    for k in ('col', 'c0out', 't1tmp', 't4out', 'logits', 'argmax0', 'dropmask', 'labels'):
+        cp(getattr(src, k), getattr(dst, k))
+
+
+def test_train_step_tiny():
     ref, mod = make_pair(TINY_CFG)
     cpu_mod = copy.deepcopy(mod)
     cpu_mod.set_backend(kernel_model.ModelBackend())
     x, labels = make_batch(2, 64, 96)
     masks = make_dropout_masks(ref, 2, torch.Generator().manual_seed(5))
     loss_r, g_ref = oracle_train(ref, x, labels, masks)
-    cpu_mod.train()
-    loss_c = cpu_mod.train_step(x, labels, dropout_masks=masks)
-    g_cpu = {n: p.grad.clone() for n, p in cpu_mod.named_parameters()}
     mod = mod.cuda().train()
     gm = {k: v.cuda() for k, v in masks.items()}
     loss_g = mod.train_step(x.cuda(), labels.cuda(), dropout_masks=gm)
     torch.cuda.synchronize()
-    g_gpu = {n: p.grad.cpu() for n, p in mod.named_parameters()}
+    g_gpu = {n: p.grad.cpu().clone() for n, p in mod.named_parameters()}
     assert abs(float(loss_g) - float(loss_r)) < 2e-3 * abs(float(loss_r))
-    assert abs(float(loss_g) - float(loss_c)) < 2e-3 * abs(float(loss_r))
-    # same rounding points: the HIP kernels must track the CPU model closely
+
+    # (1) backward from an identical forward state: the HIP backward must match the CPU kernel model
+    #     (same rounding points; only summation order and atomics differ)
+    cpu_mod.train()
+    eng_c = cpu_mod.engine(2, 64, 96, True)
+    eng_g = mod.engine(2, 64, 96, True)
+    cpu_mod.refresh_weights()
+    cpu_mod._gflat_zero()
+    _copy_engine_state(eng_g, eng_c)
+    eng_c._fwd_loss.run()
+    eng_c._bwd.run()
+    cpu_mod.bind_grads()
+    g_cpu = {n: p.grad.clone() for n, p in cpu_mod.named_parameters()}
+    assert abs(float(eng_c.loss) - float(loss_g)) < 1e-4 * abs(float(loss_g))
     rel, cos, worst = grad_report(g_cpu, g_gpu)
-    assert cos > 0.98 and rel < 0.2, (rel, cos, worst)
-    # against the fp32 oracle only the direction is stable on a random-init net with bf16 storage
+    assert rel < 2e-2 and cos > 0.9995, (rel, cos, worst)
+
+    # (2) against the fp32 oracle.  Gradients of this network at random initialisation are
+    #     hypersensitive to forward perturbations (rounding only the oracle's conv weights to bf16
+    #     moves its own gradient by tens of percent), so the yardstick is exactly that perturbation.
+    ref_b = copy.deepcopy(ref)
+    with torch.no_grad():
+        for p in ref_b.parameters():
+            if p.dim() == 4:
+                p.copy_(p.to(torch.bfloat16).float())
+    _, g_refb = oracle_train(ref_b, x, labels, masks)
+    rel_yard, cos_yard, _ = grad_report(g_ref, g_refb)
     rel_o, cos_o, worst_o = grad_report(g_ref, g_gpu)
-    rel_c, cos_c, _ = grad_report(g_ref, g_cpu)
-    assert cos_o > cos_c - 0.05, (cos_o, cos_c)
+    assert rel_o < max(3.0 * rel_yard, 0.05), (rel_o, rel_yard, cos_o, cos_yard, worst_o)
+
     # running statistics follow the oracle
     br = dict(ref.named_buffers())
     for n, b in mod.named_buffers():
