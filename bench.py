@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""DenseASPP161 training throughput on MI355X: images/s at 1024x2048, data-parallel over N GPUs.
+
+One step = im2col/stem ... classifier forward, fused bilinear-x8 + cross-entropy, full backward,
+bucketed gradient all-reduce (N > 1) and the fused Adam update, on synthetic Cityscapes-shaped
+batches already resident in HBM.  Prints ONE JSON line (rank 0).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (spec, without 2:1 sparsity)
+PEAK_HBM_GBS = 8000.0         # MI355X HBM3E peak (spec)
+
+
+def synth_batch(B, H, W, rank, device):
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(B, 3, H, W, generator=g).clamp_(-2.2, 2.7)
+    labels = torch.randint(0, 19, (B, H, W), generator=g)
+    labels[torch.rand(B, H, W, generator=g) < 0.1] = 255
+    return x.to(device), labels.to(device)
+
+
+def cpu_baseline(cfg, budget_s=30.0):
+    """The oracle (plain torch.nn fp32 DenseASPP161) forward+backward on the host cores, batch 1."""
+    import torch.nn.functional as F
+    from oracle.dense_aspp_ref import DenseASPPRef
+    threads = int(os.environ.get('OMP_NUM_THREADS', '0')) or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    ref = DenseASPPRef(cfg).train()
+
+    def one(H, W):
+        x, labels = synth_batch(1, H, W, 0, 'cpu')
+        t = time.time()
+        ref.zero_grad()
+        loss = F.cross_entropy(ref(x), labels, ignore_index=255)
+        loss.backward()
+        return time.time() - t
+
+    one(128, 256)                       # thread-pool / allocator warm-up, untimed
+    t_small = one(512, 1024)
+    if t_small * 4.5 <= budget_s:
+        t = one(1024, 2048)
+        return dict(value=1.0 / t, unit='img/s', cores=threads, kind='port',
+                    sample='1 fwd+bwd step, batch 1, 1024x2048, fp32 torch.nn oracle (%.1f s)' % t)
+    return dict(value=1.0 / t_small, unit='img/s', cores=threads, kind='port',
+                sample='1 fwd+bwd step, batch 1, 512x1024 (1024x2048 would exceed the %.0f s budget), '
+                       'fp32 torch.nn oracle (%.1f s)' % (budget_s, t_small))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=4, help='images per GPU per step')
+    ap.add_argument('--height', type=int, default=1024)
+    ap.add_argument('--width', type=int, default=2048)
+    ap.add_argument('--model', default='DenseASPP161')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    import importlib
+    import denseASPP
+    from semantic_segmentation_amd import profiling
+    from semantic_segmentation_amd.distributed import GradReducer
+    from semantic_segmentation_amd.optim import FusedAdam
+    cfg = importlib.import_module('cfgs.' + args.model).Model_CFG
+
+    torch.manual_seed(0)                                   # identical replicas on every rank
+    model = denseASPP.DenseASPP(cfg, n_class=19, output_stride=8).to(device).train()
+    opt = FusedAdam(model, lr=1e-4, weight_decay=1e-4)     # reference defaults: Adam, coupled L2 1e-4
+    B, H, W = args.batch, args.height, args.width
+    x, labels = synth_batch(B, H, W, rank, device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(99 + rank)
+    eng = model.engine(B, H, W, True)
+    reducer = GradReducer(model, eng) if world > 1 else None
+    model.refresh_weights()
+
+    def step():
+        loss = model.train_step(x, labels, generator=gen, refresh=False, reducer=reducer)
+        opt.step(grad_scale=1.0 / world)
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    sync()
+    timing = rank == 0 and not args.no_kernel_timing
+    progs = [eng._fwd, eng._fwd_loss, eng._bwd]
+    per_run = {}
+    if timing:
+        for p in progs:
+            for t, (fl, by, n) in profiling.tag_program(p).items():
+                a = per_run.setdefault(t, [0.0, 0.0, 0])
+                a[0] += fl; a[1] += by; a[2] += n
+    sync()
+    t0 = time.time()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    loss_val = float(loss)
+
+    roofline = None
+    kernels = {}
+    if timing:
+        nt = len(profiling.CLASSES)
+        ms = [0.0] * nt
+        cnt = [0] * nt
+        for p in progs:
+            m, c = p.read_timing(nt)
+            ms = [a + b for a, b in zip(ms, m)]
+            cnt = [a + b for a, b in zip(cnt, c)]
+            profiling.untag_program(p)
+        for t in range(1, nt):
+            if cnt[t]:
+                fl, by, n = per_run[t]
+                kernels[profiling.CLASSES[t]] = dict(
+                    launches_per_step=n, avg_us=1e3 * ms[t] / cnt[t], ms_per_step=ms[t] / args.steps,
+                    tflops=(fl * args.steps / (ms[t] * 1e-3) / 1e12) if fl else None,
+                    gbs=(by * args.steps / (ms[t] * 1e-3) / 1e9) if by else None)
+        mfma = {k: v for k, v in kernels.items() if v['tflops']}
+        dom = max(mfma, key=lambda k: mfma[k]['ms_per_step'])
+        roofline = dict(bound='mfma', kernel=dom, achieved=round(mfma[dom]['tflops'], 2), peak=PEAK_BF16_TFLOPS,
+                        unit='TFLOP/s', frac=round(mfma[dom]['tflops'] / PEAK_BF16_TFLOPS, 4), traffic=None,
+                        avg_launch_us=round(mfma[dom]['avg_us'], 2), launches_per_step=mfma[dom]['launches_per_step'])
+
+    if rank == 0:
+        imgs = world * B * args.steps
+        macs = model.conv_macs(H, W)
+        value = imgs / dt
+        out = {
+            'metric': 'DenseASPP161 train img/s @1024x2048' if args.model == 'DenseASPP161' and (H, W) == (1024, 2048)
+                      else '%s train img/s @%dx%d' % (args.model, H, W),
+            'value': round(value, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': '%s fwd+bwd+Adam, 19 classes, %dx%d, batch %d per GPU, bf16 storage / fp32 accumulate'
+                                   % (args.model, H, W, B), 'global_batch': world * B, 'parallelism': 'dp%d' % world},
+            'model_tflops_per_s': round(6.0 * macs * value / 1e12, 2),
+            'mfma_peak_frac_whole_step': round(6.0 * macs * value / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+            'loss': round(loss_val, 5),
+            'roofline': roofline,
+            'kernels': {k: {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items()} for k, v in kernels.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(cfg)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -366,6 +366,12 @@ int dsaspp_program_add(dsaspp_program* p, int32_t op, const void* desc, int64_t 
 int dsaspp_program_size(const dsaspp_program* p);
 /* run ops [first, last) ; last < 0 means to the end */
 int dsaspp_program_run(dsaspp_program* p, int32_t first, int32_t last, dsaspp_stream_t stream);
+/* Per-kernel timing with HIP events on the launch stream (measurement only): ops given a
+ * non-zero tag are bracketed by two events on every run until the timing is read.
+ * dsaspp_program_read_timing synchronises the recorded events, adds the elapsed milliseconds
+ * and launch counts of tag t to ms[t] / launches[t] (t < n_tags) and clears the recordings. */
+int dsaspp_program_set_tag(dsaspp_program* p, int32_t op_index, int32_t tag);
+int dsaspp_program_read_timing(dsaspp_program* p, int32_t n_tags, double* ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

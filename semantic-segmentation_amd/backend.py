@@ -18,6 +18,15 @@ class HipProgram:
     def __len__(self):
         return self.lib.dsaspp_program_size(self.handle)
 
+    def set_tag(self, op_index, tag):
+        _lib.check(self.lib.dsaspp_program_set_tag(self.handle, op_index, tag))
+
+    def read_timing(self, n_tags):
+        ms = (ctypes.c_double * n_tags)()
+        cnt = (ctypes.c_int64 * n_tags)()
+        _lib.check(self.lib.dsaspp_program_read_timing(self.handle, n_tags, ms, cnt))
+        return list(ms), list(cnt)
+
     def __del__(self):
         try:
             self.lib.dsaspp_program_destroy(self.handle)

@@ -38,7 +38,12 @@ union AnyDesc {
 };
 struct Op {
     int32_t kind;
+    int32_t tag;
     AnyDesc d;
+};
+struct Stamp {
+    int32_t tag;
+    hipEvent_t a, b;
 };
 size_t desc_size(int32_t op) {
     switch (op) {
@@ -69,10 +74,46 @@ size_t desc_size(int32_t op) {
 
 struct dsaspp_program {
     std::vector<Op> ops;
+    std::vector<Stamp> stamps;
+    bool any_tag = false;
 };
 
 extern "C" dsaspp_program* dsaspp_program_create(void) { return new (std::nothrow) dsaspp_program(); }
-extern "C" void dsaspp_program_destroy(dsaspp_program* p) { delete p; }
+extern "C" void dsaspp_program_destroy(dsaspp_program* p) {
+    if (!p) return;
+    for (auto& st : p->stamps) {
+        (void)hipEventDestroy(st.a);
+        (void)hipEventDestroy(st.b);
+    }
+    delete p;
+}
+
+extern "C" int dsaspp_program_set_tag(dsaspp_program* p, int32_t op_index, int32_t tag) {
+    DS_REQUIRE(p && op_index >= 0 && op_index < (int)p->ops.size() && tag >= 0, "program_set_tag: bad arguments");
+    p->ops[op_index].tag = tag;
+    p->any_tag = false;
+    for (auto& o : p->ops) p->any_tag = p->any_tag || o.tag != 0;
+    return 0;
+}
+
+extern "C" int dsaspp_program_read_timing(dsaspp_program* p, int32_t n_tags, double* ms, int64_t* launches) {
+    DS_REQUIRE(p && ms && launches && n_tags > 0, "program_read_timing: bad arguments");
+    int rc = 0;
+    for (auto& st : p->stamps) {
+        float t = 0.f;
+        hipError_t e = hipEventSynchronize(st.b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, st.a, st.b);
+        if (e != hipSuccess) rc = dsaspp_set_error("program_read_timing: %s", hipGetErrorString(e));
+        else if (st.tag < n_tags) {
+            ms[st.tag] += (double)t;
+            launches[st.tag] += 1;
+        }
+        (void)hipEventDestroy(st.a);
+        (void)hipEventDestroy(st.b);
+    }
+    p->stamps.clear();
+    return rc;
+}
 extern "C" int dsaspp_program_size(const dsaspp_program* p) { return p ? (int)p->ops.size() : 0; }
 
 extern "C" int dsaspp_program_add(dsaspp_program* p, int32_t op, const void* desc, int64_t desc_bytes) {
@@ -82,6 +123,7 @@ extern "C" int dsaspp_program_add(dsaspp_program* p, int32_t op, const void* des
     DS_REQUIRE((size_t)desc_bytes == want, "program_add: op %d descriptor is %lld bytes, library expects %zu (header mismatch)", op, (long long)desc_bytes, want);
     Op o;
     o.kind = op;
+    o.tag = 0;
     memset(&o.d, 0, sizeof(o.d));
     memcpy(&o.d, desc, want);
     try {
@@ -100,6 +142,14 @@ extern "C" int dsaspp_program_run(dsaspp_program* p, int32_t first, int32_t last
     for (int i = first; i < last; ++i) {
         const Op& o = p->ops[i];
         int rc = 0;
+        Stamp st;
+        const bool timed = o.tag != 0;
+        if (timed) {
+            st.tag = o.tag;
+            if (hipEventCreate(&st.a) != hipSuccess || hipEventCreate(&st.b) != hipSuccess)
+                return dsaspp_set_error("program_run: hipEventCreate failed");
+            (void)hipEventRecord(st.a, (hipStream_t)s);
+        }
         switch (o.kind) {
             case DSASPP_OP_CONV: rc = dsaspp_conv_fwd(&o.d.conv, s); break;
             case DSASPP_OP_WGRAD: rc = dsaspp_conv_wgrad(&o.d.wgrad, s); break;
@@ -128,6 +178,10 @@ extern "C" int dsaspp_program_run(dsaspp_program* p, int32_t first, int32_t last
                                             o.d.gen.cols, o.d.gen.dst_cols, s);
                 break;
             default: rc = dsaspp_set_error("program_run: unknown op %d at %d", o.kind, i);
+        }
+        if (timed) {
+            (void)hipEventRecord(st.b, (hipStream_t)s);
+            p->stamps.push_back(st);
         }
         if (rc != 0) {
             char tmp[400];

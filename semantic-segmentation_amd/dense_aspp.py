@@ -303,7 +303,7 @@ class DenseASPP(nn.Module):
         return eng.out_argmax.view(eng.B, eng.H, eng.W).clone()
 
     def train_step(self, x, labels, ignore_index=255, dropout_masks=None, generator=None, zero_grad=True,
-                   refresh=True):
+                   refresh=True, reducer=None):
         """Fused forward + bilinear-x8/cross-entropy + backward.  Leaves gradients in the flat gradient
         arena (every Parameter's .grad is a view of it) and returns the mean loss as a 1-element tensor."""
         if not self.training:
@@ -316,7 +316,10 @@ class DenseASPP(nn.Module):
             eng._loss_ignore = ignore_index
         eng.set_labels(labels)
         eng._fwd_loss.run()
-        eng._bwd.run()
+        if reducer is not None:
+            reducer.run_backward()
+        else:
+            eng._bwd.run()
         if self.features.conv0.weight.grad is None or \
                 self.features.conv0.weight.grad.data_ptr() != self._gflat.data_ptr() + 4 * self.arena.by_name['features.conv0.weight'].off:
             self.bind_grads()

@@ -1,0 +1,70 @@
+"""Data-parallel gradient reduction: one process per GPU, bucketed all-reduce over RCCL (xGMI),
+overlapped with the backward pass.
+
+The reference wraps the model in single-process nn.DataParallel (graph_seg_main.py:173), which
+broadcasts all parameters and reduces all gradients through GPU 0 every step.  Here every rank
+holds a full replica; because all gradients live in one flat arena in forward order and the
+backward program finishes them from the end of the arena towards its start, a bucket is a
+contiguous slice that becomes final at a known op index of the backward program.  The program is
+replayed in segments; after each segment the finished slice is handed to an asynchronous
+all-reduce, which RCCL runs on its own stream while the next segment computes.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, model, engine, bucket_mb=25.0, group=None):
+        self.model, self.engine, self.group = model, engine, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        gflat = model._gflat
+        n = gflat.numel()
+        ops = engine._bwd.keepalive if hasattr(engine._bwd, 'keepalive') else engine._bwd.ops
+        # last op index that writes each arena entry
+        last_write = {}
+        for i, (kind, f) in enumerate(ops):
+            for k, v in f.items():
+                if hasattr(v, 't') and v.t is gflat:
+                    last_write[v.off] = i
+        entries = sorted(model.arena.entries, key=lambda e: e.off)
+        per_bucket = max(1, int(bucket_mb * 1024 * 1024 / 4))
+        self.buckets = []          # (lo, hi, ready_op_index), from the end of the arena to its start
+        hi = n
+        ready = -1
+        lo_cur = n
+        for e in reversed(entries):
+            ready = max(ready, last_write.get(e.off, -1))
+            lo_cur = e.off
+            if hi - lo_cur >= per_bucket:
+                self.buckets.append((lo_cur, hi, ready))
+                hi = lo_cur
+                ready = -1
+        if hi > 0:
+            self.buckets.append((0, hi, max(ready, max(last_write.values()) if last_write else -1)))
+        # ready indices must be non-decreasing along the bucket order for segment replay
+        fixed = []
+        run = -1
+        for lo, hi_, r in self.buckets:
+            run = max(run, r)
+            fixed.append((lo, hi_, run))
+        self.buckets = fixed
+        self.n_ops = len(ops)
+
+    def run_backward(self):
+        """Replay the backward program in segments, launching one async all-reduce per finished bucket."""
+        eng = self.engine
+        gflat = self.model._gflat
+        handles = []
+        pos = 0
+        for lo, hi, ready in self.buckets:
+            end = ready + 1
+            if end > pos:
+                eng._bwd.run(first=pos, last=end)
+                pos = end
+            if self.world > 1:
+                handles.append(dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if pos < self.n_ops:
+            eng._bwd.run(first=pos, last=self.n_ops)
+        for h in handles:
+            h.wait()
+        return 1.0 / self.world          # scale to apply to the summed gradients (FusedAdam grad_scale)

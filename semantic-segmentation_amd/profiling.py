@@ -1,0 +1,70 @@
+"""Kernel classes, their algorithmic work, and live HIP-event timing of a recorded program.
+
+The convolution entry points dispatch on the output-channel count to a few tile instantiations;
+`kernel_class` mirrors that dispatch so that timing groups coincide with the kernel symbols a
+profiler shows.  Algorithmic work: 2*M*cout*taps*cin flops for a convolution or weight-gradient
+launch; bytes for the fused upsample + cross-entropy kernel (low-res logits read + labels read +
+low-res gradient written).
+"""
+
+CLASSES = ['untimed',
+           'conv_kernel<128,192,2,2>', 'conv_kernel<128,128,2,2>', 'conv_kernel<256,48,4,1>',
+           'conv_kernel<128,64,2,2>', 'conv_kernel<128,32,4,1>',
+           'wgrad_kernel<64,192,1,4>', 'wgrad_kernel<192,64,2,2>', 'wgrad_kernel<128,128,2,2>',
+           'upce_kernel<19>']
+
+
+def kernel_class(kind, f):
+    if kind == 'conv':
+        co = f['cout']
+        if co <= 32:
+            return 5
+        if co <= 48:
+            return 3
+        if co <= 64:
+            return 4
+        pad192, pad128 = (co + 191) // 192 * 192, (co + 127) // 128 * 128
+        return 1 if pad192 <= pad128 else 2
+    if kind == 'wgrad':
+        co = f['cout']
+        if co <= 64:
+            return 6
+        if co > 128 and (co + 191) // 192 * 192 <= (co + 127) // 128 * 128:
+            return 7
+        return 8
+    if kind == 'upce':
+        return 9
+    return 0
+
+
+def work(kind, f):
+    """(flops, bytes) of one launch: algorithmic, i.e. what the operation needs, not what a kernel moves."""
+    if kind in ('conv', 'wgrad'):
+        M = f['n_img'] * f['H'] * f['W']
+        return 2.0 * M * f['cout'] * f['taps'] * f['cin'], 0.0
+    if kind == 'upce':
+        m = f['n_img'] * f['h'] * f['w']
+        # fp32 low-res logits read (n_class), int64 labels read, fp32 low-res gradient written
+        return 0.0, m * f['n_class'] * 4.0 + m * 64 * 8.0 + m * f['n_class'] * 4.0
+    return 0.0, 0.0
+
+
+def tag_program(prog):
+    """Tag every MFMA / loss op of a HipProgram for event timing; returns per-class (flops, bytes) per run."""
+    per = {}
+    for i, (kind, f) in enumerate(prog.keepalive):
+        t = kernel_class(kind, f)
+        if t:
+            prog.set_tag(i, t)
+            fl, by = work(kind, f)
+            a = per.setdefault(t, [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += by
+            a[2] += 1
+    return per
+
+
+def untag_program(prog):
+    for i, (kind, f) in enumerate(prog.keepalive):
+        if kernel_class(kind, f):
+            prog.set_tag(i, 0)
