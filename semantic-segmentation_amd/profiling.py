@@ -49,6 +49,37 @@ def work(kind, f):
     return 0.0, 0.0
 
 
+def role(kind, f):
+    """Finer grouping used for reporting only: what the launch does in the network."""
+    if kind == 'conv':
+        if f.get('g') is not None:
+            return 'dgrad1x1->slab'
+        if f.get('epi_relu'):
+            return 'dgrad3x3' if f['taps'] == 9 else 'dgrad1x1'
+        return 'fwd3x3' if f['taps'] == 9 else 'fwd1x1'
+    if kind == 'wgrad':
+        return 'wgrad3x3' if f['taps'] == 9 else 'wgrad1x1'
+    return kind
+
+
+def tag_program_fine(prog, table):
+    """Tag ops by (kernel class, role); `table` maps the key to a tag and is extended in place."""
+    per = {}
+    for i, (kind, f) in enumerate(prog.keepalive):
+        t = kernel_class(kind, f)
+        if not t:
+            continue
+        key = CLASSES[t] + ' ' + role(kind, f)
+        tag = table.setdefault(key, len(table) + 1)
+        prog.set_tag(i, tag)
+        fl, by = work(kind, f)
+        a = per.setdefault(tag, [0.0, 0.0, 0])
+        a[0] += fl
+        a[1] += by
+        a[2] += 1
+    return per
+
+
 def tag_program(prog):
     """Tag every MFMA / loss op of a HipProgram for event timing; returns per-class (flops, bytes) per run."""
     per = {}
