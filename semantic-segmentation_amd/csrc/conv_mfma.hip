@@ -2,8 +2,11 @@
 //
 // GEMM view: P = pixels (N*H*W), Q = output channels, K = taps*cin (tap-major, channel-minor).
 // A block computes a BP x BQ tile with 4 waves; operands are staged through LDS in K-steps of
-// 32 as [row][32] bf16 rows (64 B) with an XOR chunk swizzle that makes the ds_read_b128
-// fragment reads conflict-free.  The activation tile passes through registers on its way to
+// 64 channels as [row][64] bf16 rows (128 B, one full cache line per pixel) with an XOR chunk
+// swizzle that makes the ds_read_b128 fragment reads conflict-free.  The K loop keeps the
+// instruction count per MFMA low: row pointers are rebuilt only when the filter tap changes,
+// loads are branch-free (clamped address + select), and the prologue variant is a template
+// parameter.  The activation tile passes through registers on its way to
 // LDS, where the consumer's BatchNorm scale/shift, the ReLU and the zero padding of the
 // dilated halo are applied, so neither the normalised tensor nor the concatenated input ever
 // exists in memory.  Weights are the MFMA A operand (rows = channels) and pixels the B operand,
@@ -13,25 +16,33 @@
 
 namespace {
 
-constexpr int BK = 32;
+constexpr int BK = 64;            // K-step: 64 channels = one full 128-byte line per pixel row
 
-__device__ __forceinline__ int swz4(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+// 128-byte LDS rows hold 8 chunks of 16 B; XOR the chunk index with (row/2)%8 so that the
+// ds_read_b128 fragment reads (16 rows x one chunk column per 16-lane group) are conflict-free.
+__device__ __forceinline__ int swz8(int row) { return (row >> 1) & 7; }
 
-template <int BP, int BQ, int WP, int WQ>
-__global__ __launch_bounds__(256) void conv_kernel(const dsaspp_conv_desc d, const int M, const int nQ,
-                                                   const int nblocks) {
-    static_assert(WP * WQ == 4, "4 waves");
+// PRO selects the prologue compiled into the activation staging path:
+//   0 = none (raw copy), 1 = per-channel scale/shift (+ReLU when in_relu), 2 = general
+//   (optional scale/shift, optional ReLU, per-image channel mask)
+template <int BP, int BQ, int WP, int WQ, int PRO>
+__global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_kernel(const dsaspp_conv_desc d, const int M,
+                                                                                  const int nQ, const int nblocks) {
+    constexpr int NW = WP * WQ, NT = 64 * NW;     // waves / threads per block
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     constexpr int A_BYTES = BP * BK * 2, W_BYTES = BQ * BK * 2;
-    constexpr int AR = BP / 64;                   // activation chunks per thread
-    constexpr int WCH = BQ * 4;                   // weight chunks per tile
-    constexpr int WR = (WCH + 255) / 256;
+    constexpr int RSTEP = NT / 8;                 // rows covered by one pass of the block's threads
+    static_assert(BP % RSTEP == 0, "activation tile rows");
+    constexpr int AR = BP / RSTEP;                // activation chunks per thread per K-step
+    constexpr int WCH = BQ * 8;                   // weight chunks per tile
+    constexpr int WR = (WCH + NT - 1) / NT;
     constexpr int TP = BP / WP, TQ = BQ / WQ, MP = TP / 16, MQ = TQ / 16;
     static_assert(TP % 16 == 0 && TQ % 16 == 0, "wave tile");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;
-    unsigned char* Ws = smem + 2 * A_BYTES;
-    float* tab = reinterpret_cast<float*>(smem + 2 * A_BYTES + 2 * W_BYTES);
+    unsigned char* Ws = smem + A_BYTES;
+    float* tab = reinterpret_cast<float*>(smem + A_BYTES + W_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = xcd_remap(blockIdx.x, nblocks);
@@ -40,24 +51,26 @@ __global__ __launch_bounds__(256) void conv_kernel(const dsaspp_conv_desc d, con
     const int H = d.H, W = d.W, cin = d.cin, cout = d.cout, taps = d.taps, dil = d.dil;
     const int hw = H * W;
     const int Ktot = taps * cin;
-    const int ksteps = (Ktot + BK - 1) / BK;
+    const int csteps = (cin + BK - 1) / BK;
+    const int ksteps = taps * csteps;
     const bool has_scale = d.in_scale != nullptr;
-    const bool has_pro = has_scale || d.in_relu || d.in_mask != nullptr;
 
-    if (has_scale) {
-        for (int c = tid; c < cin; c += 256) {
+    if (PRO != 0 && has_scale) {
+        for (int c = tid; c < cin; c += NT) {
             tab[c] = d.in_scale[c];
             tab[cin + c] = d.in_shift[c];
         }
     }
+    const float relu_floor = d.in_relu ? 0.f : -3.0e38f;
 
-    // ---- per-thread staging coordinates
-    const int ck = tid & 3;
+    // ---- per-thread staging coordinates: chunk column ck of rows (tid>>3) + RSTEP*i
+    const int ck = tid & 7;
+    const int arow0 = tid >> 3;
     int a_n[AR], a_h[AR], a_w[AR];
     bool a_ok[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int m = p_base + (tid >> 2) + 64 * i;
+        const int m = p_base + arow0 + RSTEP * i;
         a_ok[i] = m < M;
         const int mm = a_ok[i] ? m : 0;
         a_n[i] = mm / hw;
@@ -65,78 +78,88 @@ __global__ __launch_bounds__(256) void conv_kernel(const dsaspp_conv_desc d, con
         a_h[i] = rem / W;
         a_w[i] = rem - a_h[i] * W;
     }
-    bool w_ok[WR];
-    int w_row[WR];
-#pragma unroll
-    for (int i = 0; i < WR; ++i) {
-        const int idx = tid + 256 * i;
-        w_row[i] = idx >> 2;
-        w_ok[i] = (idx < WCH) && (q_base + w_row[i] < cout);
-    }
-
     const u16* xg = reinterpret_cast<const u16*>(d.x);
     const u16* wg = reinterpret_cast<const u16*>(d.w);
+    const u16* w_ptr[WR];
+    bool w_ok[WR];
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+        const int idx = tid + NT * i;
+        const int row = idx >> 3;
+        w_ok[i] = (idx < WCH) && (q_base + row < cout);
+        w_ptr[i] = wg + (w_ok[i] ? (int64_t)(q_base + row) * Ktot : 0);
+    }
 
-    uint4 areg[AR], wreg[WR];
-    bool aval[AR];
-    int tap = 0, c = ck * 8;            // (tap, channel) of this thread's chunk in the current K-step
-    while (c >= cin) { c -= cin; ++tap; }
-    int lc = c;                         // channel of the chunk held in areg (for the prologue)
-
-    auto gload = [&]() {
+    // per-tap row pointers (recomputed only when the tap changes)
+    const u16* a_ptr[AR];
+    bool a_val[AR];
+    auto tap_setup = [&](const int tap) {
         int dy = 0, dx = 0;
         if (taps == 9) {
             const int ty = tap / 3;
             dy = (ty - 1) * dil;
             dx = (tap - ty * 3 - 1) * dil;
         }
-        const bool kvalid = tap < taps;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int hh = a_h[i] + dy, ww = a_w[i] + dx;
-            const bool ok = a_ok[i] && kvalid && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-            aval[i] = ok;
-            if (ok) {
-                const int64_t pix = ((int64_t)a_n[i] * H + hh) * W + ww;
-                areg[i] = *reinterpret_cast<const uint4*>(xg + pix * d.ldx + c);
-            } else {
-                areg[i] = make_uint4(0, 0, 0, 0);
-            }
+            const bool ok = a_ok[i] && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+            a_val[i] = ok;
+            const int64_t pix = ((int64_t)a_n[i] * H + hh) * W + ww;
+            a_ptr[i] = xg + (ok ? pix * d.ldx : 0);
         }
-#pragma unroll
-        for (int i = 0; i < WR; ++i) {
-            if (w_ok[i] && kvalid) {
-                wreg[i] = *reinterpret_cast<const uint4*>(wg + (int64_t)(q_base + w_row[i]) * Ktot + (int64_t)tap * cin + c);
-            } else {
-                wreg[i] = make_uint4(0, 0, 0, 0);
-            }
-        }
-        lc = c;
-        c += BK;
-        while (c >= cin) { c -= cin; ++tap; }
     };
 
-    auto sstore = [&](int buf) {
+    uint4 areg[AR], wreg[WR];
+    bool lval[AR];                      // validity of the chunks held in areg
+    int lc = 0;                         // channel of the chunks held in areg (for the prologue tables)
+    int tap = 0, c0 = 0;                // position of the next K-step to load
+
+    auto gload = [&]() {
+        const int c = c0 + ck * 8;
+        const bool cvalid = c < cin;
+        const int co = cvalid ? c : 0;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            areg[i] = *reinterpret_cast<const uint4*>(a_ptr[i] + co);     // always a mapped address
+            lval[i] = a_val[i] && cvalid;
+        }
+        const int ko = cvalid ? tap * cin + c : 0;
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            uint4 v = *reinterpret_cast<const uint4*>(w_ptr[i] + ko);
+            const bool ok = w_ok[i] && cvalid;
+            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+            wreg[i] = v;
+        }
+        lc = co;
+        c0 += BK;
+        if (c0 >= cin) {
+            c0 = 0;
+            ++tap;
+            if (tap < taps) tap_setup(tap);
+        }
+    };
+
+    auto sstore = [&]() {
         float sc[8], sh[8];
-        if (has_scale && lc < cin) {
+        if (PRO == 1 || (PRO == 2 && has_scale)) {
             load8f(tab + lc, sc);
             load8f(tab + cin + lc, sh);
         }
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             uint4 v = areg[i];
-            if (has_pro && aval[i]) {
+            if (PRO != 0) {
                 float f[8];
                 unpack8(v, f);
-                if (has_scale) {
+                if (PRO == 1 || has_scale) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
                 }
-                if (d.in_relu) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
-                }
-                if (d.in_mask) {
+                for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], relu_floor);
+                if (PRO == 2 && d.in_mask) {
                     float mk[8];
                     load8f(d.in_mask + (int64_t)a_n[i] * d.in_mask_ld + lc, mk);
 #pragma unroll
@@ -144,14 +167,17 @@ __global__ __launch_bounds__(256) void conv_kernel(const dsaspp_conv_desc d, con
                 }
                 v = pack8(f);
             }
-            const int row = (tid >> 2) + 64 * i;
-            *reinterpret_cast<uint4*>(As + buf * A_BYTES + row * 64 + ((ck ^ swz4(row)) << 4)) = v;
+            const bool ok = lval[i];      // zero padding (halo, K tail, rows past M) comes AFTER the prologue
+            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+            const int row = arow0 + RSTEP * i;
+            *reinterpret_cast<uint4*>(As + row * 128 + ((ck ^ swz8(row)) << 4)) = v;
         }
 #pragma unroll
         for (int i = 0; i < WR; ++i) {
-            if (tid + 256 * i < WCH) {
-                const int row = w_row[i];
-                *reinterpret_cast<uint4*>(Ws + buf * W_BYTES + row * 64 + ((ck ^ swz4(row)) << 4)) = wreg[i];
+            const int idx = tid + NT * i;
+            if (idx < WCH) {
+                const int row = idx >> 3;
+                *reinterpret_cast<uint4*>(Ws + row * 128 + ((ck ^ swz8(row)) << 4)) = wreg[i];
             }
         }
     };
@@ -159,145 +185,179 @@ __global__ __launch_bounds__(256) void conv_kernel(const dsaspp_conv_desc d, con
     // ---- MFMA fragment coordinates
     const int fr = lane & 15, fc = lane >> 4;
     const int wp = wave % WP, wq = wave / WP;
-    const int frag_off = fr * 64 + ((fc ^ swz4(fr)) << 4);
+    const int frag_off0 = fr * 128 + ((fc ^ swz8(fr)) << 4);
+    const int frag_off1 = fr * 128 + (((4 + fc) ^ swz8(fr)) << 4);
     f32x4 acc[MQ][MP];
 #pragma unroll
     for (int i = 0; i < MQ; ++i)
 #pragma unroll
         for (int j = 0; j < MP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    tap_setup(0);
     gload();
     __syncthreads();   // scale/shift table visible
-    sstore(0);
-    __syncthreads();
-
     for (int s = 0; s < ksteps; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < ksteps) gload();
-        bf16x8 af[MP], wf[MQ];
+        sstore();                              // K-step s: registers -> LDS (prologue applied here)
+        __syncthreads();
+        if (s + 1 < ksteps) gload();           // K-step s+1 in flight while step s is multiplied
 #pragma unroll
-        for (int j = 0; j < MP; ++j)
-            af[j] = *reinterpret_cast<const bf16x8*>(As + buf * A_BYTES + (wp * TP + j * 16) * 64 + frag_off);
-#pragma unroll
-        for (int i = 0; i < MQ; ++i)
-            wf[i] = *reinterpret_cast<const bf16x8*>(Ws + buf * W_BYTES + (wq * TQ + i * 16) * 64 + frag_off);
-#pragma unroll
-        for (int i = 0; i < MQ; ++i)
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fo = ks ? frag_off1 : frag_off0;
+            bf16x8 af[MP], wf[MQ];
 #pragma unroll
             for (int j = 0; j < MP; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-        if (s + 1 < ksteps) sstore(buf ^ 1);
-        __syncthreads();
+                af[j] = *reinterpret_cast<const bf16x8*>(As + (wp * TP + j * 16) * 128 + fo);
+#pragma unroll
+            for (int i = 0; i < MQ; ++i)
+                wf[i] = *reinterpret_cast<const bf16x8*>(Ws + (wq * TQ + i * 16) * 128 + fo);
+#pragma unroll
+            for (int i = 0; i < MQ; ++i)
+#pragma unroll
+                for (int j = 0; j < MP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                       // every wave is done reading before the next store
     }
 
-    // ---- epilogue: lane holds channels q..q+3 of pixel p for each (i, j)
+    // ---- epilogue.  The accumulators hold 4 consecutive channels of one pixel per lane; going
+    // straight to memory from there touches 16 different pixel rows per instruction.  Each wave
+    // instead passes its tile through a private LDS patch, 16 pixels at a time, and re-reads it so
+    // that LPR consecutive lanes cover one contiguous run of CBW channels of a pixel (128 B in
+    // fp32): the gradient-slab read-modify-write and the NHWC stores become full-line accesses.
+    constexpr int CBW = (TQ % 32 == 0) ? 32 : 16;   // channels per column block
+    constexpr int LPR = CBW / 4;                    // lanes per pixel row (one float4 each)
+    constexpr int RPP = 64 / LPR;                   // pixel rows per pass
+    constexpr int NCB = TQ / CBW;
+    constexpr int NRP = 16 / RPP;
+    constexpr int ROWF = TQ + 4;                    // padded row stride in floats (bank spread)
+    static_assert(NW * 16 * ROWF * 4 + 5 * BQ * 4 <= A_BYTES + W_BYTES, "epilogue LDS fits in the staging buffers");
+    float* stage = reinterpret_cast<float*>(smem) + wave * (16 * ROWF);
+    float* epar = reinterpret_cast<float*>(smem) + NW * 16 * ROWF;     // [5][BQ]: bias, scale, shift, mean, rstd
     const int rep = blockIdx.x % DS_R;
     const bool want_stats = (d.stat_acc != nullptr) && (d.g == nullptr);
     const bool want_s = d.s_acc != nullptr;
+    const bool need_ref = d.epi_relu || want_s;
+    for (int c = tid; c < BQ; c += NT) {
+        const int q = q_base + c;
+        const bool ok = q < cout;
+        epar[c] = (ok && d.bias) ? d.bias[q] : 0.f;
+        epar[BQ + c] = (ok && d.e_scale) ? d.e_scale[q] : 1.f;
+        epar[2 * BQ + c] = (ok && d.e_scale) ? d.e_shift[q] : 0.f;
+        epar[3 * BQ + c] = (ok && want_s) ? d.e_mean[q] : 0.f;
+        epar[4 * BQ + c] = (ok && want_s) ? d.e_rstd[q] : 1.f;
+    }
+    const int er = lane / LPR, ec = lane % LPR;
+    float st_a[NCB][4], st_b[NCB][4];
 #pragma unroll
-    for (int i = 0; i < MQ; ++i) {
-        const int q = q_base + wq * TQ + i * 16 + fc * 4;
-        const bool q_ok = q < cout;
-        float st_sum[4] = {0, 0, 0, 0}, st_sq[4] = {0, 0, 0, 0};   // stats or S1/S2 partials
-        float bias4[4] = {0, 0, 0, 0}, es[4] = {1, 1, 1, 1}, eh[4] = {0, 0, 0, 0}, em[4] = {0, 0, 0, 0},
-              er[4] = {1, 1, 1, 1};
-        if (q_ok) {
-            if (d.bias) { const float4 b = *reinterpret_cast<const float4*>(d.bias + q); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
-            if (d.e_scale) {
-                const float4 a = *reinterpret_cast<const float4*>(d.e_scale + q); es[0] = a.x; es[1] = a.y; es[2] = a.z; es[3] = a.w;
-                const float4 b = *reinterpret_cast<const float4*>(d.e_shift + q); eh[0] = b.x; eh[1] = b.y; eh[2] = b.z; eh[3] = b.w;
-            }
-            if (want_s) {
-                const float4 a = *reinterpret_cast<const float4*>(d.e_mean + q); em[0] = a.x; em[1] = a.y; em[2] = a.z; em[3] = a.w;
-                const float4 b = *reinterpret_cast<const float4*>(d.e_rstd + q); er[0] = b.x; er[1] = b.y; er[2] = b.z; er[3] = b.w;
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { st_a[cb][e] = 0.f; st_b[cb][e] = 0.f; }
+
+#pragma unroll
+    for (int j = 0; j < MP; ++j) {
+        __syncthreads();          // previous patch fully consumed (first pass: K-loop reads done, epar written)
+#pragma unroll
+        for (int i = 0; i < MQ; ++i)
+            *reinterpret_cast<f32x4*>(stage + fr * ROWF + i * 16 + fc * 4) = acc[i][j];
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int cl = wq * TQ + cb * CBW + ec * 4;      // channel within the block tile
+            const int q = q_base + cl;
+#pragma unroll
+            for (int rp = 0; rp < NRP; ++rp) {
+                const int r = rp * RPP + er;
+                const int p = p_base + wp * TP + j * 16 + r;
+                if (!(p < M && q < cout)) continue;
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(stage + r * ROWF + cb * CBW + ec * 4);
+                float v[4] = {a4[0] + epar[cl], a4[1] + epar[cl + 1], a4[2] + epar[cl + 2], a4[3] + epar[cl + 3]};
+                if (d.out_mask) {
+                    const int n = p / hw;
+                    const float4 mk = *reinterpret_cast<const float4*>(d.out_mask + (int64_t)n * d.out_mask_ld + q);
+                    v[0] *= mk.x; v[1] *= mk.y; v[2] *= mk.z; v[3] *= mk.w;
+                }
+                float rf[4] = {0, 0, 0, 0};
+                if (need_ref) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(d.ref) + (int64_t)p * d.ldref + q);
+                    rf[0] = bf_lo(rr.x); rf[1] = bf_hi(rr.x); rf[2] = bf_lo(rr.y); rf[3] = bf_hi(rr.y);
+                }
+                if (d.epi_relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pre = d.e_scale ? fmaf(rf[e], epar[BQ + cl + e], epar[2 * BQ + cl + e]) : rf[e];
+                        if (!(pre > 0.f)) v[e] = 0.f;
+                    }
+                }
+                if (want_s) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        st_a[cb][e] += v[e];
+                        st_b[cb][e] += v[e] * ((rf[e] - epar[3 * BQ + cl + e]) * epar[4 * BQ + cl + e]);
+                    }
+                }
+                if (d.g) {
+                    float* gp = d.g + (int64_t)p * d.ldg + q;
+                    float4 t = make_float4(v[0] * epar[BQ + cl], v[1] * epar[BQ + cl + 1], v[2] * epar[BQ + cl + 2],
+                                           v[3] * epar[BQ + cl + 3]);
+                    if (d.g_accumulate) {
+                        const float4 o = *reinterpret_cast<const float4*>(gp);
+                        t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+                    }
+                    *reinterpret_cast<float4*>(gp) = t;
+                } else if (d.y_f32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.y) + (int64_t)p * d.ldy + q) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (want_stats) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { st_a[cb][e] += v[e]; st_b[cb][e] += v[e] * v[e]; }
+                    }
+                } else {
+                    uint2 o;
+                    o.x = pack_bf2(v[0], v[1]);
+                    o.y = pack_bf2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(d.y) + (int64_t)p * d.ldy + q) = o;
+                    if (want_stats) {
+                        const float s0 = bf_lo(o.x), s1 = bf_hi(o.x), s2 = bf_lo(o.y), s3 = bf_hi(o.y);
+                        st_a[cb][0] += s0; st_a[cb][1] += s1; st_a[cb][2] += s2; st_a[cb][3] += s3;
+                        st_b[cb][0] += s0 * s0; st_b[cb][1] += s1 * s1; st_b[cb][2] += s2 * s2; st_b[cb][3] += s3 * s3;
+                    }
+                }
             }
         }
+    }
+    if (want_stats || want_s) {
+        float* base = (want_s ? d.s_acc : d.stat_acc) + (size_t)rep * 2 * cout;
 #pragma unroll
-        for (int j = 0; j < MP; ++j) {
-            const int p = p_base + wp * TP + j * 16 + fr;
-            if (!(q_ok && p < M)) continue;
-            float v[4] = {acc[i][j][0] + bias4[0], acc[i][j][1] + bias4[1], acc[i][j][2] + bias4[2], acc[i][j][3] + bias4[3]};
-            if (d.out_mask) {
-                const int n = p / hw;
-                const float4 mk = *reinterpret_cast<const float4*>(d.out_mask + (int64_t)n * d.out_mask_ld + q);
-                v[0] *= mk.x; v[1] *= mk.y; v[2] *= mk.z; v[3] *= mk.w;
-            }
-            float rf[4] = {0, 0, 0, 0};
-            if (d.epi_relu || want_s) {
-                const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(d.ref) + (int64_t)p * d.ldref + q);
-                rf[0] = bf_lo(rr.x); rf[1] = bf_hi(rr.x); rf[2] = bf_lo(rr.y); rf[3] = bf_hi(rr.y);
-            }
-            if (d.epi_relu) {
+        for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pre = d.e_scale ? fmaf(rf[r], es[r], eh[r]) : rf[r];
-                    if (!(pre > 0.f)) v[r] = 0.f;
+            for (int e = 0; e < 4; ++e) {
+                // lanes that share ec (same channels) differ in er: reduce over them
+#pragma unroll
+                for (int o = LPR; o < 64; o <<= 1) {
+                    st_a[cb][e] += __shfl_xor(st_a[cb][e], o, 64);
+                    st_b[cb][e] += __shfl_xor(st_b[cb][e], o, 64);
                 }
             }
-            if (want_s) {
+            const int q = q_base + wq * TQ + cb * CBW + ec * 4;
+            if (er == 0 && q < cout) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    st_sum[r] += v[r];
-                    st_sq[r] += v[r] * ((rf[r] - em[r]) * er[r]);
-                }
-            }
-            if (d.g) {
-                float* gp = d.g + (int64_t)p * d.ldg + q;
-                float4 t = make_float4(v[0] * es[0], v[1] * es[1], v[2] * es[2], v[3] * es[3]);
-                if (d.g_accumulate) {
-                    const float4 o = *reinterpret_cast<const float4*>(gp);
-                    t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
-                }
-                *reinterpret_cast<float4*>(gp) = t;
-            } else if (d.y_f32) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.y) + (int64_t)p * d.ldy + q) = make_float4(v[0], v[1], v[2], v[3]);
-                if (want_stats) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { st_sum[r] += v[r]; st_sq[r] += v[r] * v[r]; }
-                }
-            } else {
-                uint2 o;
-                o.x = pack_bf2(v[0], v[1]);
-                o.y = pack_bf2(v[2], v[3]);
-                *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(d.y) + (int64_t)p * d.ldy + q) = o;
-                if (want_stats) {
-                    const float s0 = bf_lo(o.x), s1 = bf_hi(o.x), s2 = bf_lo(o.y), s3 = bf_hi(o.y);
-                    st_sum[0] += s0; st_sum[1] += s1; st_sum[2] += s2; st_sum[3] += s3;
-                    st_sq[0] += s0 * s0; st_sq[1] += s1 * s1; st_sq[2] += s2 * s2; st_sq[3] += s3 * s3;
-                }
-            }
-        }
-        if (want_stats || want_s) {
-            // reduce over the 16 lanes that share fc (pixels), then one atomic per channel per wave
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    st_sum[r] += __shfl_xor(st_sum[r], o, 64);
-                    st_sq[r] += __shfl_xor(st_sq[r], o, 64);
-                }
-            }
-            if (fr == 0 && q_ok) {
-                float* base = (want_s ? d.s_acc : d.stat_acc) + (size_t)rep * 2 * cout;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    atomicAdd(base + q + r, st_sum[r]);
-                    atomicAdd(base + cout + q + r, st_sq[r]);
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(base + q + e, st_a[cb][e]);
+                    atomicAdd(base + cout + q + e, st_b[cb][e]);
                 }
             }
         }
     }
 }
 
-template <int BP, int BQ, int WP, int WQ>
-int launch(const dsaspp_conv_desc& d, hipStream_t s) {
+template <int BP, int BQ, int WP, int WQ, int PRO>
+int launch_pro(const dsaspp_conv_desc& d, hipStream_t s) {
     const int64_t M64 = (int64_t)d.n_img * d.H * d.W;
     const int M = (int)M64;
     const int nP = (M + BP - 1) / BP, nQ = (d.cout + BQ - 1) / BQ;
     const int nblocks = nP * nQ;
-    const size_t lds = 2 * (size_t)(BP + BQ) * BK * 2 + (d.in_scale ? (size_t)d.cin * 8 : 0);
+    const size_t lds = (size_t)(BP + BQ) * BK * 2 + ((PRO != 0 && d.in_scale) ? (size_t)d.cin * 8 : 0);
     DS_REQUIRE(lds <= 160 * 1024, "conv_fwd: LDS request %zu too large", lds);
-    auto kern = conv_kernel<BP, BQ, WP, WQ>;
+    auto kern = conv_kernel<BP, BQ, WP, WQ, PRO>;
     if (lds > 64 * 1024) {
         static thread_local bool done = false;
         if (!done) {
@@ -305,9 +365,17 @@ int launch(const dsaspp_conv_desc& d, hipStream_t s) {
             done = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, s, d, M, nQ, nblocks);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * WP * WQ), lds, s, d, M, nQ, nblocks);
     DS_LAUNCH_CHECK("conv_fwd");
     return 0;
+}
+
+template <int BP, int BQ, int WP, int WQ>
+int launch(const dsaspp_conv_desc& d, hipStream_t s) {
+    if (d.in_mask) return launch_pro<BP, BQ, WP, WQ, 2>(d, s);
+    if (d.in_scale) return launch_pro<BP, BQ, WP, WQ, 1>(d, s);
+    if (d.in_relu) return launch_pro<BP, BQ, WP, WQ, 2>(d, s);
+    return launch_pro<BP, BQ, WP, WQ, 0>(d, s);
 }
 
 }  // namespace
@@ -343,6 +411,6 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
     if (co <= 48) return launch<256, 48, 4, 1>(d, s);
     if (co <= 64) return launch<128, 64, 2, 2>(d, s);
     const int pad192 = (co + 191) / 192 * 192, pad128 = (co + 127) / 128 * 128;
-    if (pad192 <= pad128) return launch<128, 192, 2, 2>(d, s);
-    return launch<128, 128, 2, 2>(d, s);
+    if (pad192 <= pad128) return launch<128, 192, 2, 4>(d, s);
+    return launch<128, 128, 2, 4>(d, s);
 }

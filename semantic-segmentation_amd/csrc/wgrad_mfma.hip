@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dsaspp_wgrad_desc d, c
     float* tab = reinterpret_cast<float*>(smem + 2 * Z_BYTES + 2 * X_BYTES);  // scale[BC], shift[BC]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bid = blockIdx.x;
+    // blocks that share a pixel range (and so the dz tile) get neighbouring logical ids -> same XCD / L2
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int ct = bid % nC; bid /= nC;
     const int qt = bid % nQ; bid /= nQ;
     const int tap = bid % d.taps;
@@ -232,7 +233,7 @@ int launch(const dsaspp_wgrad_desc& d, hipStream_t s) {
     const int base_blocks = nQ * nC * d.taps;
     int ksplit = d.ksplit;
     const int max_split = (M + 4 * BKP - 1) / (4 * BKP);   // at least 4 K-steps per block
-    if (ksplit <= 0) ksplit = (1024 + base_blocks - 1) / base_blocks;
+    if (ksplit <= 0) ksplit = 1024 / base_blocks;      // at most 1024 blocks: two full rounds at 2 blocks per CU
     if (ksplit > max_split) ksplit = max_split;
     if (ksplit < 1) ksplit = 1;
     int chunk = (M + ksplit - 1) / ksplit;
