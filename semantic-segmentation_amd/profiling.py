@@ -8,7 +8,7 @@ low-res gradient written).
 """
 
 CLASSES = ['untimed',
-           'conv_kernel<128,192,2,2>', 'conv_kernel<128,128,2,2>', 'conv_kernel<256,48,4,1>',
+           'conv_kernel<128,192,2,4>', 'conv_kernel<128,128,2,4>', 'conv_kernel<256,48,4,1>',
            'conv_kernel<128,64,2,2>', 'conv_kernel<128,32,4,1>',
            'wgrad_kernel<64,192,1,4>', 'wgrad_kernel<192,64,2,2>', 'wgrad_kernel<128,128,2,2>',
            'upce_kernel<19>']
