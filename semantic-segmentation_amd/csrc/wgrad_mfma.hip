@@ -2,32 +2,50 @@
 //
 // dw[q][tap][c] += sum_m dz[m][q] * A[m + off(tap)][c],  A = mask * relu(x*scale+shift) recomputed
 // here from the slab (the normalised activations are never stored).  GEMM view: rows = output
-// channels q, cols = input channels c, K = pixels.  NHWC data is channel-contiguous but the MFMA
-// fragments need 8 consecutive K (pixels) per lane, so each thread loads an 8-pixel x 8-channel
-// patch (eight 16-byte loads), transposes it in registers while applying the prologue, and writes
-// eight [channel][8 pixels] chunks into a [channel][64 pixel] LDS image (128-byte rows, XOR
-// swizzled).  One block owns a (BQ x BC) tile of one tap over a pixel range; partial sums of the
-// pixel ranges are combined with fp32 atomics.
+// channels q, cols = input channels c, K = pixels.  NHWC data is channel-contiguous while both MFMA
+// operands need 8 consecutive K (pixels) per lane.  The tiles are therefore staged in their natural
+// [pixel][channel] layout -- plain 16-byte chunk copies, the prologue applied on the way exactly as in
+// the forward kernel -- and the fragments are fetched with the CDNA4 transposing LDS read
+// (ds_read_b64_tr_b16): each 16-lane group reads a 4-pixel x 16-channel block and every lane receives
+// the 4 pixels of its own channel.  One block owns a (BQ x BC) tile of one filter tap over a pixel
+// range; the partial sums of the pixel ranges are combined with fp32 atomics.
 #include "common.h"
 
 namespace {
 
-constexpr int BKP = 64;  // pixels per K-step
+constexpr int BKP = 64;   // pixels per K-step
+constexpr int PADE = 8;   // row padding in elements (16 B): spreads the 4 rows of a transposed read over the banks
 
-__device__ __forceinline__ int swz8(int row) { return (row >> 1) & 7; }
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-template <int BQ, int BC, int WQ, int WC>
-__global__ __launch_bounds__(256) void wgrad_kernel(const dsaspp_wgrad_desc d, const int M, const int nQ,
-                                                    const int nC, const int chunk) {
-    static_assert(BQ + BC == 256, "one 8x8 patch per thread");
-    static_assert(WQ * WC == 4, "4 waves");
-    constexpr int Z_BYTES = BQ * BKP * 2, X_BYTES = BC * BKP * 2;
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const int half_stride) {
+    // two transposed reads: pixels k..k+3 and k+4..k+7 of this lane's channel
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0 + half_stride));
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int BQ, int BC, int WQ, int WC, int PRO>
+__global__ __launch_bounds__(64 * WQ * WC, (WQ * WC == 8) ? 4 : 2) void wgrad_kernel(const dsaspp_wgrad_desc d, const int M,
+                                                                                   const int nQ, const int nC,
+                                                                                   const int chunk) {
+    constexpr int NW = WQ * WC, NT = 64 * NW;
+    constexpr int ZS = BQ + PADE, XS = BC + PADE;               // LDS row strides in elements
+    constexpr int Z_BYTES = BKP * ZS * 2, X_BYTES = BKP * XS * 2;
+    constexpr int ZCH = BQ / 8, XCH = BC / 8;                   // 16-byte chunks per pixel row
+    constexpr int ZLPR = (ZCH <= 4) ? 4 : (ZCH <= 8) ? 8 : (ZCH <= 16) ? 16 : 32;    // lanes per row (pow2 >= chunks)
+    constexpr int XLPR = (XCH <= 4) ? 4 : (XCH <= 8) ? 8 : (XCH <= 16) ? 16 : 32;
+    constexpr int ZRPP = NT / ZLPR, XRPP = NT / XLPR;           // rows per pass
+    constexpr int ZR = (BKP + ZRPP - 1) / ZRPP, XR = (BKP + XRPP - 1) / XRPP;
     constexpr int TQ = BQ / WQ, TC = BC / WC, MQ = TQ / 16, MC = TC / 16;
+    static_assert(TQ % 16 == 0 && TC % 16 == 0, "wave tile");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Zs = smem;
-    unsigned char* Xs = smem + 2 * Z_BYTES;
-    float* tab = reinterpret_cast<float*>(smem + 2 * Z_BYTES + 2 * X_BYTES);  // scale[BC], shift[BC]
+    unsigned char* Xs = smem + Z_BYTES;
+    float* tab = reinterpret_cast<float*>(smem + Z_BYTES + X_BYTES);   // scale[BC], shift[BC]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // blocks that share a pixel range (and so the dz tile) get neighbouring logical ids -> same XCD / L2
@@ -43,17 +61,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dsaspp_wgrad_desc d, c
     const int m_end = min(M, m_begin + chunk);
     const int ksteps = (m_end - m_begin + BKP - 1) / BKP;
     const bool has_scale = d.in_scale != nullptr;
-    const bool has_pro = has_scale || d.in_relu || d.in_mask != nullptr;
-    const bool need_nhw = (d.taps == 9) || (d.in_mask != nullptr);
+    const bool need_nhw = (d.taps == 9) || (PRO == 2 && d.in_mask != nullptr);
+    const float relu_floor = d.in_relu ? 0.f : -3.0e38f;
 
-    if (has_scale) {
-        for (int c = tid; c < BC; c += 256) {
+    if (PRO != 0 && has_scale) {
+        for (int c = tid; c < BC; c += NT) {
             const bool ok = c_base + c < cin;
             tab[c] = ok ? d.in_scale[c_base + c] : 0.f;
             tab[BC + c] = ok ? d.in_shift[c_base + c] : 0.f;
         }
     }
-
     int dy = 0, dx = 0;
     if (d.taps == 9) {
         const int ty = tap / 3;
@@ -61,115 +78,101 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dsaspp_wgrad_desc d, c
         dx = (tap - ty * 3 - 1) * d.dil;
     }
 
-    // ---- staging role: threads [0,BQ) transpose dz, threads [BQ,256) transpose the activations
-    const bool is_z = tid < BQ;
-    const int t2 = is_z ? tid : tid - BQ;
-    const int po = t2 & 7;              // pixel octet within the 64-pixel step
-    const int cg = t2 >> 3;             // channel group (8 channels)
-    const int ch0 = (is_z ? q_base : c_base) + cg * 8;
-    const bool ch_ok = ch0 < (is_z ? cout : cin);
-    const u16* zg = reinterpret_cast<const u16*>(d.dz);
-    const u16* xg = reinterpret_cast<const u16*>(d.x);
+    // ---- staging coordinates
+    const int zc = tid % ZLPR, zr0 = tid / ZLPR;       // chunk column / first row of the dz tile
+    const int xc = tid % XLPR, xr0 = tid / XLPR;
+    const bool zc_ok = zc < ZCH && (q_base + zc * 8) < cout;
+    const bool xc_ok = xc < XCH && (c_base + xc * 8) < cin;
+    const u16* zg = reinterpret_cast<const u16*>(d.dz) + (zc_ok ? q_base + zc * 8 : 0);
+    const u16* xg = reinterpret_cast<const u16*>(d.x) + (xc_ok ? c_base + xc * 8 : 0);
 
-    uint4 reg[8];
-    unsigned okmask = 0;     // bit j: pixel j of the patch is a real (in-bounds) sample
-    int img[8];              // image index per pixel (only kept for in_mask)
+    uint4 zreg[ZR], xreg[XR];
+    bool xval[XR];
+    int ximg[XR];
 
-    auto gload = [&](int step) {
-        const int m0 = m_begin + step * BKP + po * 8;
-        okmask = 0;
-        if (is_z) {
+    auto gload = [&](const int step) {
+        const int m0 = m_begin + step * BKP;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int m = m0 + j;
-                if (ch_ok && m < m_end) {
-                    reg[j] = *reinterpret_cast<const uint4*>(zg + (int64_t)m * d.lddz + ch0);
-                } else {
-                    reg[j] = make_uint4(0, 0, 0, 0);
-                }
-            }
-        } else {
-            int n = 0, h = 0, w = 0;
+        for (int i = 0; i < ZR; ++i) {
+            const int row = zr0 + ZRPP * i;
+            const int m = m0 + row;
+            const bool ok = zc_ok && row < BKP && m < m_end;
+            uint4 v = *reinterpret_cast<const uint4*>(zg + (int64_t)(ok ? m : m_begin) * d.lddz);
+            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+            zreg[i] = v;
+        }
+        int n0 = 0, h0 = 0, w0 = 0;
+        if (need_nhw) {
+            const int mm = min(m0, M - 1);
+            n0 = mm / hw;
+            const int rem = mm - n0 * hw;
+            h0 = rem / W;
+            w0 = rem - h0 * W;
+        }
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const int row = xr0 + XRPP * i;
+            const int m = m0 + row;
+            bool ok = xc_ok && row < BKP && m < m_end;
+            int64_t pix = m;
             if (need_nhw) {
-                const int mm = min(m0, M - 1);
-                n = mm / hw;
-                const int rem = mm - n * hw;
-                h = rem / W;
-                w = rem - h * W;
+                int n = n0, h = h0, w = w0 + row;
+                while (w >= W) { w -= W; ++h; }
+                while (h >= H) { h -= H; ++n; }
+                const int hh = h + dy, ww = w + dx;
+                ok = ok && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+                pix = ((int64_t)n * H + hh) * W + ww;
+                ximg[i] = n;
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int m = m0 + j;
-                bool ok = ch_ok && m < m_end;
-                int64_t pix = m;
-                if (need_nhw) {
-                    const int hh = h + dy, ww = w + dx;
-                    ok = ok && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-                    pix = ((int64_t)n * H + hh) * W + ww;
-                    img[j] = n;
-                    // advance (n, h, w) to the next pixel
-                    if (++w == W) { w = 0; if (++h == H) { h = 0; ++n; } }
-                }
-                if (ok) {
-                    reg[j] = *reinterpret_cast<const uint4*>(xg + pix * d.ldx + ch0);
-                    okmask |= 1u << j;
-                } else {
-                    reg[j] = make_uint4(0, 0, 0, 0);
-                }
-            }
+            xreg[i] = *reinterpret_cast<const uint4*>(xg + (ok ? pix : 0) * d.ldx);
+            xval[i] = ok;
         }
     };
 
-    auto sstore = [&](int buf) {
-        unsigned char* base = is_z ? (Zs + buf * Z_BYTES) : (Xs + buf * X_BYTES);
-        uint32_t out[8][4];   // [channel e][pixel pair k]
-        if (is_z || !has_pro) {
-            const uint32_t* r32 = reinterpret_cast<const uint32_t*>(reg);
+    auto sstore = [&]() {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t a = r32[(2 * k) * 4 + (e >> 1)], b = r32[(2 * k + 1) * 4 + (e >> 1)];
-                    out[e][k] = (e & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
-                }
-            }
-        } else {
-            float sc[8], sh[8];
-            if (has_scale) {
-                load8f(tab + cg * 8, sc);
-                load8f(tab + BC + cg * 8, sh);
-            }
-            float f[8][8];   // [pixel j][channel e]
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                unpack8(reg[j], f[j]);
-                const bool ok = (okmask >> j) & 1;
-                float mk[8];
-                if (d.in_mask && ok) load8f(d.in_mask + (int64_t)img[j] * d.in_mask_ld + ch0, mk);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float v = f[j][e];
-                    if (has_scale) v = fmaf(v, sc[e], sh[e]);
-                    if (d.in_relu) v = fmaxf(v, 0.f);
-                    if (d.in_mask && ok) v *= mk[e];
-                    f[j][e] = ok ? v : 0.f;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) out[e][k] = pack_bf2(f[2 * k][e], f[2 * k + 1][e]);
+        for (int i = 0; i < ZR; ++i) {
+            const int row = zr0 + ZRPP * i;
+            if (zc < ZCH && row < BKP) *reinterpret_cast<uint4*>(Zs + (row * ZS + zc * 8) * 2) = zreg[i];
+        }
+        float sc[8], sh[8];
+        if (PRO == 1 || (PRO == 2 && has_scale)) {
+            load8f(tab + (xc < XCH ? xc : 0) * 8, sc);
+            load8f(tab + BC + (xc < XCH ? xc : 0) * 8, sh);
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int row = cg * 8 + e;
-            *reinterpret_cast<uint4*>(base + row * 128 + ((po ^ swz8(row)) << 4)) =
-                make_uint4(out[e][0], out[e][1], out[e][2], out[e][3]);
+        for (int i = 0; i < XR; ++i) {
+            const int row = xr0 + XRPP * i;
+            uint4 v = xreg[i];
+            if (PRO != 0) {
+                float f[8];
+                unpack8(v, f);
+                if (PRO == 1 || has_scale) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], relu_floor);
+                if (PRO == 2 && d.in_mask) {
+                    float mk[8];
+                    load8f(d.in_mask + (int64_t)ximg[i] * d.in_mask_ld + (xc_ok ? c_base + xc * 8 : 0), mk);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] *= mk[e];
+                }
+                v = pack8(f);
+            }
+            const bool ok = xval[i];       // zero padding comes after the prologue
+            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+            if (xc < XCH && row < BKP) *reinterpret_cast<uint4*>(Xs + (row * XS + xc * 8) * 2) = v;
         }
     };
 
-    const int fr = lane & 15, fc = lane >> 4;
+    // ---- fragment addressing: lane (g = lane/16, i16 = lane%16) supplies row g*8 + i16/4 (+4 for the
+    // second half), columns 4*(i16%4).. of a 16-channel block and receives channel i16, pixels g*8..g*8+7.
+    const int g16 = lane >> 4, i16 = lane & 15;
     const int wq = wave % WQ, wc = wave / WQ;
+    const int zfrag = ((g16 * 8 + (i16 >> 2)) * ZS + wq * TQ + (i16 & 3) * 4) * 2;
+    const int xfrag = ((g16 * 8 + (i16 >> 2)) * XS + wc * TC + (i16 & 3) * 4) * 2;
     f32x4 acc[MQ][MC];
 #pragma unroll
     for (int i = 0; i < MQ; ++i)
@@ -178,38 +181,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dsaspp_wgrad_desc d, c
 
     if (ksteps > 0) {
         gload(0);
-        __syncthreads();
-        sstore(0);
-        __syncthreads();
+        __syncthreads();      // scale/shift table visible
         for (int s = 0; s < ksteps; ++s) {
-            const int buf = s & 1;
+            sstore();
+            __syncthreads();
             if (s + 1 < ksteps) gload(s + 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 zf[MQ], xf[MC];
-                const int chunkk = ks * 4 + fc;
 #pragma unroll
-                for (int i = 0; i < MQ; ++i) {
-                    const int row = wq * TQ + i * 16 + fr;
-                    zf[i] = *reinterpret_cast<const bf16x8*>(Zs + buf * Z_BYTES + row * 128 + ((chunkk ^ swz8(row)) << 4));
-                }
+                for (int i = 0; i < MQ; ++i) zf[i] = tr_frag(Zs + zfrag + (ks * 32 * ZS + i * 16) * 2, 4 * ZS * 2);
 #pragma unroll
-                for (int j = 0; j < MC; ++j) {
-                    const int row = wc * TC + j * 16 + fr;
-                    xf[j] = *reinterpret_cast<const bf16x8*>(Xs + buf * X_BYTES + row * 128 + ((chunkk ^ swz8(row)) << 4));
-                }
+                for (int j = 0; j < MC; ++j) xf[j] = tr_frag(Xs + xfrag + (ks * 32 * XS + j * 16) * 2, 4 * XS * 2);
 #pragma unroll
                 for (int i = 0; i < MQ; ++i)
 #pragma unroll
                     for (int j = 0; j < MC; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[i], xf[j], acc[i][j], 0, 0, 0);
             }
-            if (s + 1 < ksteps) sstore(buf ^ 1);
             __syncthreads();
         }
     }
 
     // ---- epilogue: acc[i][j][r] is (q = q0 + i*16 + fc*4 + r, c = c0 + j*16 + fr)
+    const int fr = lane & 15, fc = lane >> 4;
     const int Ktot = d.taps * cin;
 #pragma unroll
     for (int i = 0; i < MQ; ++i) {
@@ -226,29 +221,39 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dsaspp_wgrad_desc d, c
     }
 }
 
-template <int BQ, int BC, int WQ, int WC>
-int launch(const dsaspp_wgrad_desc& d, hipStream_t s) {
+template <int BQ, int BC, int WQ, int WC, int PRO>
+int launch_pro(const dsaspp_wgrad_desc& d, hipStream_t s) {
     const int M = d.n_img * d.H * d.W;
     const int nQ = (d.cout + BQ - 1) / BQ, nC = (d.cin + BC - 1) / BC;
     const int base_blocks = nQ * nC * d.taps;
     int ksplit = d.ksplit;
     const int max_split = (M + 4 * BKP - 1) / (4 * BKP);   // at least 4 K-steps per block
-    if (ksplit <= 0) ksplit = 1024 / base_blocks;      // at most 1024 blocks: two full rounds at 2 blocks per CU
+    if (ksplit <= 0) ksplit = 1024 / base_blocks;          // about two rounds of resident blocks
     if (ksplit > max_split) ksplit = max_split;
     if (ksplit < 1) ksplit = 1;
     int chunk = (M + ksplit - 1) / ksplit;
     chunk = (chunk + BKP - 1) / BKP * BKP;
     ksplit = (M + chunk - 1) / chunk;
-    const size_t lds = 2 * (size_t)(BQ + BC) * BKP * 2 + (d.in_scale ? (size_t)BC * 8 : 0);
-    auto kern = wgrad_kernel<BQ, BC, WQ, WC>;
-    static thread_local bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        done = true;
+    const size_t lds = (size_t)BKP * (BQ + PADE + BC + PADE) * 2 + ((PRO != 0 && d.in_scale) ? (size_t)BC * 8 : 0);
+    auto kern = wgrad_kernel<BQ, BC, WQ, WC, PRO>;
+    if (lds > 64 * 1024) {
+        static thread_local bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            done = true;
+        }
     }
-    hipLaunchKernelGGL(kern, dim3(base_blocks * ksplit), dim3(256), lds, s, d, M, nQ, nC, chunk);
+    hipLaunchKernelGGL(kern, dim3(base_blocks * ksplit), dim3(64 * WQ * WC), lds, s, d, M, nQ, nC, chunk);
     DS_LAUNCH_CHECK("conv_wgrad");
     return 0;
+}
+
+template <int BQ, int BC, int WQ, int WC>
+int launch(const dsaspp_wgrad_desc& d, hipStream_t s) {
+    if (d.in_mask) return launch_pro<BQ, BC, WQ, WC, 2>(d, s);
+    if (d.in_scale) return launch_pro<BQ, BC, WQ, WC, 1>(d, s);
+    if (d.in_relu) return launch_pro<BQ, BC, WQ, WC, 2>(d, s);
+    return launch_pro<BQ, BC, WQ, WC, 0>(d, s);
 }
 
 }  // namespace
@@ -266,7 +271,10 @@ extern "C" int dsaspp_conv_wgrad(const dsaspp_wgrad_desc* dp, dsaspp_stream_t st
     DS_REQUIRE(((uintptr_t)d.x & 15) == 0 && ((uintptr_t)d.dz & 15) == 0, "conv_wgrad: operands must be 16-byte aligned");
     DS_REQUIRE((d.in_scale == nullptr) == (d.in_shift == nullptr), "conv_wgrad: in_scale/in_shift must come together");
     if (d.in_mask) DS_REQUIRE(d.in_mask_ld % 4 == 0, "conv_wgrad: in_mask_ld must be a multiple of 4");
-    if (d.cout <= 64) return launch<64, 192, 1, 4>(d, s);
-    if (d.cout > 128 && (d.cout + 191) / 192 * 192 <= (d.cout + 127) / 128 * 128) return launch<192, 64, 2, 2>(d, s);
-    return launch<128, 128, 2, 2>(d, s);
+    const int co = d.cout;
+    if (co <= 32) return launch<32, 192, 1, 4>(d, s);
+    if (co <= 48) return launch<48, 192, 1, 4>(d, s);
+    if (co <= 64) return launch<64, 192, 1, 4>(d, s);
+    if (co > 128 && (co + 191) / 192 * 192 <= (co + 127) / 128 * 128) return launch<192, 128, 4, 2>(d, s);
+    return launch<128, 128, 2, 4>(d, s);
 }

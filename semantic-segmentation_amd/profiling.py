@@ -10,8 +10,8 @@ low-res gradient written).
 CLASSES = ['untimed',
            'conv_kernel<128,192,2,4>', 'conv_kernel<128,128,2,4>', 'conv_kernel<256,48,4,1>',
            'conv_kernel<128,64,2,2>', 'conv_kernel<128,32,4,1>',
-           'wgrad_kernel<64,192,1,4>', 'wgrad_kernel<192,64,2,2>', 'wgrad_kernel<128,128,2,2>',
-           'upce_kernel<19>']
+           'wgrad_kernel<64,192,1,4>', 'wgrad_kernel<192,128,4,2>', 'wgrad_kernel<128,128,2,4>',
+           'upce_kernel<19>', 'wgrad_kernel<48,192,1,4>', 'wgrad_kernel<32,192,1,4>']
 
 
 def kernel_class(kind, f):
@@ -27,6 +27,10 @@ def kernel_class(kind, f):
         return 1 if pad192 <= pad128 else 2
     if kind == 'wgrad':
         co = f['cout']
+        if co <= 32:
+            return 11
+        if co <= 48:
+            return 10
         if co <= 64:
             return 6
         if co > 128 and (co + 191) // 192 * 192 <= (co + 127) // 128 * 128:
