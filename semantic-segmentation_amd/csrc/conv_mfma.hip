@@ -253,33 +253,57 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
 #pragma unroll
         for (int e = 0; e < 4; ++e) { st_a[cb][e] = 0.f; st_b[cb][e] = 0.f; }
 
+    __syncthreads();              // K-loop LDS reads finished in every wave; epar visible
 #pragma unroll
     for (int j = 0; j < MP; ++j) {
-        __syncthreads();          // previous patch fully consumed (first pass: K-loop reads done, epar written)
+        // The patch is private to the wave and LDS executes a wave's accesses in order, so no
+        // block barrier is needed between the write and the read-back; only the compiler must not
+        // reorder them.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < MQ; ++i)
             *reinterpret_cast<f32x4*>(stage + fr * ROWF + i * 16 + fc * 4) = acc[i][j];
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // phase 1: issue every global load of this 16-pixel group before any dependent store
+        constexpr int NI = NCB * NRP;
+        bool ok_[NI];
+        int p_[NI], q_[NI], cl_[NI];
+        f32x4 a4_[NI];
+        float4 gold_[NI], mk_[NI];
+        uint2 rr_[NI];
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
-            const int cl = wq * TQ + cb * CBW + ec * 4;      // channel within the block tile
-            const int q = q_base + cl;
 #pragma unroll
             for (int rp = 0; rp < NRP; ++rp) {
+                const int it = cb * NRP + rp;
+                const int cl = wq * TQ + cb * CBW + ec * 4;      // channel within the block tile
+                const int q = q_base + cl;
                 const int r = rp * RPP + er;
                 const int p = p_base + wp * TP + j * 16 + r;
-                if (!(p < M && q < cout)) continue;
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(stage + r * ROWF + cb * CBW + ec * 4);
-                float v[4] = {a4[0] + epar[cl], a4[1] + epar[cl + 1], a4[2] + epar[cl + 2], a4[3] + epar[cl + 3]};
-                if (d.out_mask) {
-                    const int n = p / hw;
-                    const float4 mk = *reinterpret_cast<const float4*>(d.out_mask + (int64_t)n * d.out_mask_ld + q);
-                    v[0] *= mk.x; v[1] *= mk.y; v[2] *= mk.z; v[3] *= mk.w;
-                }
+                const bool ok = p < M && q < cout;
+                ok_[it] = ok; p_[it] = p; q_[it] = q; cl_[it] = cl;
+                a4_[it] = *reinterpret_cast<const f32x4*>(stage + r * ROWF + cb * CBW + ec * 4);
+                const int64_t pc = ok ? p : 0;
+                const int qc = ok ? q : 0;
+                if (need_ref) rr_[it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(d.ref) + pc * d.ldref + qc);
+                if (d.g && d.g_accumulate) gold_[it] = *reinterpret_cast<const float4*>(d.g + pc * d.ldg + qc);
+                if (d.out_mask) mk_[it] = *reinterpret_cast<const float4*>(d.out_mask + (pc / hw) * d.out_mask_ld + qc);
+            }
+        }
+        // phase 2: arithmetic and stores
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+            for (int rp = 0; rp < NRP; ++rp) {
+                const int it = cb * NRP + rp;
+                if (!ok_[it]) continue;
+                const int cl = cl_[it], q = q_[it];
+                const int64_t p = p_[it];
+                float v[4] = {a4_[it][0] + epar[cl], a4_[it][1] + epar[cl + 1], a4_[it][2] + epar[cl + 2], a4_[it][3] + epar[cl + 3]};
+                if (d.out_mask) { v[0] *= mk_[it].x; v[1] *= mk_[it].y; v[2] *= mk_[it].z; v[3] *= mk_[it].w; }
                 float rf[4] = {0, 0, 0, 0};
                 if (need_ref) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(d.ref) + (int64_t)p * d.ldref + q);
-                    rf[0] = bf_lo(rr.x); rf[1] = bf_hi(rr.x); rf[2] = bf_lo(rr.y); rf[3] = bf_hi(rr.y);
+                    rf[0] = bf_lo(rr_[it].x); rf[1] = bf_hi(rr_[it].x); rf[2] = bf_lo(rr_[it].y); rf[3] = bf_hi(rr_[it].y);
                 }
                 if (d.epi_relu) {
 #pragma unroll
@@ -296,16 +320,13 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
                     }
                 }
                 if (d.g) {
-                    float* gp = d.g + (int64_t)p * d.ldg + q;
+                    float* gp = d.g + p * d.ldg + q;
                     float4 t = make_float4(v[0] * epar[BQ + cl], v[1] * epar[BQ + cl + 1], v[2] * epar[BQ + cl + 2],
                                            v[3] * epar[BQ + cl + 3]);
-                    if (d.g_accumulate) {
-                        const float4 o = *reinterpret_cast<const float4*>(gp);
-                        t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
-                    }
+                    if (d.g_accumulate) { t.x += gold_[it].x; t.y += gold_[it].y; t.z += gold_[it].z; t.w += gold_[it].w; }
                     *reinterpret_cast<float4*>(gp) = t;
                 } else if (d.y_f32) {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.y) + (int64_t)p * d.ldy + q) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.y) + p * d.ldy + q) = make_float4(v[0], v[1], v[2], v[3]);
                     if (want_stats) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { st_a[cb][e] += v[e]; st_b[cb][e] += v[e] * v[e]; }
@@ -314,7 +335,7 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
                     uint2 o;
                     o.x = pack_bf2(v[0], v[1]);
                     o.y = pack_bf2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(d.y) + (int64_t)p * d.ldy + q) = o;
+                    *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(d.y) + p * d.ldy + q) = o;
                     if (want_stats) {
                         const float s0 = bf_lo(o.x), s1 = bf_hi(o.x), s2 = bf_lo(o.y), s3 = bf_hi(o.y);
                         st_a[cb][0] += s0; st_a[cb][1] += s1; st_a[cb][2] += s2; st_a[cb][3] += s3;
