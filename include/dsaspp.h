@@ -44,7 +44,7 @@ const char* dsaspp_last_error(void);
  *   if (epi_relu) { pre = ref[m*ldref+c] * e_scale[c] + e_shift[c] (ref itself when
  *                   e_scale is NULL); if (pre <= 0) v = 0; }
  *   if (s_acc)   { s_acc[rep][c] += v;  s_acc[rep][cout+c] += v * (ref - e_mean[c]) * e_rstd[c]; }
- *   if (g)       { t = v * (e_scale ? e_scale[c] : 1);  g[m*ldg+c] = (g_accumulate ? g + t : t); }
+ *   if (g)       { t = v * (e_scale ? e_scale[c] : 1);  g[m*ldg+c] = (g_accumulate ? g + t : t); }   (fp32 or bf16 slab)
  *   else         { y[m*ldy+c] = v (bf16, or fp32 when y_f32);
  *                  if (stat_acc) { stat_acc[rep][c] += v_stored; stat_acc[rep][cout+c] += v_stored^2; } }
  * where rep = blockIdx % DSASPP_STAT_REPLICAS and the stat buffers are fp32
@@ -77,9 +77,10 @@ typedef struct dsaspp_conv_desc {
     const float* e_mean;
     const float* e_rstd;
     float* s_acc;             /* [R][2*cout] sum(v), sum(v*xhat) or NULL */
-    float* g;                 /* fp32 gradient slab [M][ldg] or NULL */
+    void* g;                  /* gradient slab [M][ldg] (fp32, or bf16 when g_bf16) or NULL */
     int32_t ldg;
     int32_t g_accumulate;
+    int32_t g_bf16;
 } dsaspp_conv_desc;
 
 int dsaspp_conv_fwd(const dsaspp_conv_desc* d, dsaspp_stream_t stream);
@@ -194,7 +195,7 @@ int dsaspp_bn_act(const dsaspp_bnact_desc* d, dsaspp_stream_t stream);
  *   colsum[c] += v (when non-NULL; plain fp32 atomics) */
 typedef struct dsaspp_gradx_desc {
     int64_t M; int32_t C; int32_t hw;       /* hw = pixels per image (for mask row lookup) */
-    const float* g; int32_t ldg;
+    const void* g; int32_t ldg; int32_t g_bf16;   /* gradient slab: fp32, or bf16 when g_bf16 */
     const float* corr1; const float* corr2;
     const void* xs; int32_t ldxs; const float* s_mean; const float* s_rstd;
     const float* mask; int32_t mask_ld;

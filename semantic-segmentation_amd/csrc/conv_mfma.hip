@@ -12,6 +12,8 @@
 // exists in memory.  Weights are the MFMA A operand (rows = channels) and pixels the B operand,
 // so every lane ends up holding 4 consecutive channels of one pixel: 8-byte NHWC stores into
 // the channel slice of the feature slab replace torch.cat.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -25,7 +27,9 @@ __device__ __forceinline__ int swz8(int row) { return (row >> 1) & 7; }
 // PRO selects the prologue compiled into the activation staging path:
 //   0 = none (raw copy), 1 = per-channel scale/shift (+ReLU when in_relu), 2 = general
 //   (optional scale/shift, optional ReLU, per-image channel mask)
-template <int BP, int BQ, int WP, int WQ, int PRO>
+// EPI selects the epilogue: 0 = plain store (+bias, +dropout mask, +statistics), 1 = store masked by a
+// reference pre-activation with BatchNorm-backward sums (3x3 data gradient), 2 = gradient-slab store/accumulate.
+template <int BP, int BQ, int WP, int WQ, int PRO, int EPI>
 __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_kernel(const dsaspp_conv_desc d, const int M,
                                                                                   const int nQ, const int nblocks) {
     constexpr int NW = WP * WQ, NT = 64 * NW;     // waves / threads per block
@@ -234,9 +238,10 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
     float* stage = reinterpret_cast<float*>(smem) + wave * (16 * ROWF);
     float* epar = reinterpret_cast<float*>(smem) + NW * 16 * ROWF;     // [5][BQ]: bias, scale, shift, mean, rstd
     const int rep = blockIdx.x % DS_R;
-    const bool want_stats = (d.stat_acc != nullptr) && (d.g == nullptr);
-    const bool want_s = d.s_acc != nullptr;
-    const bool need_ref = d.epi_relu || want_s;
+    const bool want_stats = (EPI != 2) && (d.stat_acc != nullptr);
+    const bool want_s = (EPI != 0) && d.s_acc != nullptr;
+    const bool need_ref = (EPI != 0) && (d.epi_relu || want_s);
+    const bool acc_g = (EPI == 2) && d.g_accumulate;
     for (int c = tid; c < BQ; c += NT) {
         const int q = q_base + c;
         const bool ok = q < cout;
@@ -254,6 +259,38 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
         for (int e = 0; e < 4; ++e) { st_a[cb][e] = 0.f; st_b[cb][e] = 0.f; }
 
     __syncthreads();              // K-loop LDS reads finished in every wave; epar visible
+    // phase 0: every global load the epilogue needs (reference activations, old gradient-slab values,
+    // dropout mask) is issued here for the whole wave tile, so the block pays one memory round trip
+    // instead of one per 16-pixel group
+    constexpr int NI = NCB * NRP;
+    bool ok_[MP][NI];
+    float4 gold_[(EPI == 2) ? MP : 1][NI];
+    uint2 rr_[(EPI != 0) ? MP : 1][NI];
+#pragma unroll
+    for (int j = 0; j < MP; ++j) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+            for (int rp = 0; rp < NRP; ++rp) {
+                const int it = cb * NRP + rp;
+                const int q = q_base + wq * TQ + cb * CBW + ec * 4;
+                const int p = p_base + wp * TP + j * 16 + rp * RPP + er;
+                const bool ok = p < M && q < cout;
+                ok_[j][it] = ok;
+                const int64_t pc = ok ? p : 0;
+                const int qc = ok ? q : 0;
+                if (EPI != 0 && need_ref) rr_[j][it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(d.ref) + pc * d.ldref + qc);
+                if (EPI == 2 && acc_g) {
+                    if (d.g_bf16) {
+                        const uint2 gb = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(d.g) + pc * d.ldg + qc);
+                        gold_[j][it] = make_float4(bf_lo(gb.x), bf_hi(gb.x), bf_lo(gb.y), bf_hi(gb.y));
+                    } else {
+                        gold_[j][it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.g) + pc * d.ldg + qc);
+                    }
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < MP; ++j) {
         // The patch is private to the wave and LDS executes a wave's accesses in order, so no
@@ -264,67 +301,58 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
         for (int i = 0; i < MQ; ++i)
             *reinterpret_cast<f32x4*>(stage + fr * ROWF + i * 16 + fc * 4) = acc[i][j];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // phase 1: issue every global load of this 16-pixel group before any dependent store
-        constexpr int NI = NCB * NRP;
-        bool ok_[NI];
-        int p_[NI], q_[NI], cl_[NI];
         f32x4 a4_[NI];
-        float4 gold_[NI], mk_[NI];
-        uint2 rr_[NI];
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-            for (int rp = 0; rp < NRP; ++rp) {
-                const int it = cb * NRP + rp;
-                const int cl = wq * TQ + cb * CBW + ec * 4;      // channel within the block tile
-                const int q = q_base + cl;
-                const int r = rp * RPP + er;
-                const int p = p_base + wp * TP + j * 16 + r;
-                const bool ok = p < M && q < cout;
-                ok_[it] = ok; p_[it] = p; q_[it] = q; cl_[it] = cl;
-                a4_[it] = *reinterpret_cast<const f32x4*>(stage + r * ROWF + cb * CBW + ec * 4);
-                const int64_t pc = ok ? p : 0;
-                const int qc = ok ? q : 0;
-                if (need_ref) rr_[it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(d.ref) + pc * d.ldref + qc);
-                if (d.g && d.g_accumulate) gold_[it] = *reinterpret_cast<const float4*>(d.g + pc * d.ldg + qc);
-                if (d.out_mask) mk_[it] = *reinterpret_cast<const float4*>(d.out_mask + (pc / hw) * d.out_mask_ld + qc);
-            }
-        }
+            for (int rp = 0; rp < NRP; ++rp)
+                a4_[cb * NRP + rp] = *reinterpret_cast<const f32x4*>(stage + (rp * RPP + er) * ROWF + cb * CBW + ec * 4);
         // phase 2: arithmetic and stores
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
             for (int rp = 0; rp < NRP; ++rp) {
                 const int it = cb * NRP + rp;
-                if (!ok_[it]) continue;
-                const int cl = cl_[it], q = q_[it];
-                const int64_t p = p_[it];
+                if (!ok_[j][it]) continue;
+                const int cl = wq * TQ + cb * CBW + ec * 4;      // channel within the block tile
+                const int q = q_base + cl;
+                const int64_t p = p_base + wp * TP + j * 16 + rp * RPP + er;
                 float v[4] = {a4_[it][0] + epar[cl], a4_[it][1] + epar[cl + 1], a4_[it][2] + epar[cl + 2], a4_[it][3] + epar[cl + 3]};
-                if (d.out_mask) { v[0] *= mk_[it].x; v[1] *= mk_[it].y; v[2] *= mk_[it].z; v[3] *= mk_[it].w; }
-                float rf[4] = {0, 0, 0, 0};
-                if (need_ref) {
-                    rf[0] = bf_lo(rr_[it].x); rf[1] = bf_hi(rr_[it].x); rf[2] = bf_lo(rr_[it].y); rf[3] = bf_hi(rr_[it].y);
+                if (d.out_mask) {
+                    const float4 mk = *reinterpret_cast<const float4*>(d.out_mask + (p / hw) * d.out_mask_ld + q);
+                    v[0] *= mk.x; v[1] *= mk.y; v[2] *= mk.z; v[3] *= mk.w;
                 }
-                if (d.epi_relu) {
+                float rf[4] = {0, 0, 0, 0};
+                if (EPI != 0 && need_ref) {
+                    const uint2 rr = rr_[j][it];
+                    rf[0] = bf_lo(rr.x); rf[1] = bf_hi(rr.x); rf[2] = bf_lo(rr.y); rf[3] = bf_hi(rr.y);
+                }
+                if (EPI != 0 && d.epi_relu) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float pre = d.e_scale ? fmaf(rf[e], epar[BQ + cl + e], epar[2 * BQ + cl + e]) : rf[e];
                         if (!(pre > 0.f)) v[e] = 0.f;
                     }
                 }
-                if (want_s) {
+                if (EPI != 0 && want_s) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         st_a[cb][e] += v[e];
                         st_b[cb][e] += v[e] * ((rf[e] - epar[3 * BQ + cl + e]) * epar[4 * BQ + cl + e]);
                     }
                 }
-                if (d.g) {
-                    float* gp = d.g + p * d.ldg + q;
+                if (EPI == 2) {
                     float4 t = make_float4(v[0] * epar[BQ + cl], v[1] * epar[BQ + cl + 1], v[2] * epar[BQ + cl + 2],
                                            v[3] * epar[BQ + cl + 3]);
-                    if (d.g_accumulate) { t.x += gold_[it].x; t.y += gold_[it].y; t.z += gold_[it].z; t.w += gold_[it].w; }
-                    *reinterpret_cast<float4*>(gp) = t;
+                    if (acc_g) { t.x += gold_[j][it].x; t.y += gold_[j][it].y; t.z += gold_[j][it].z; t.w += gold_[j][it].w; }
+                    if (d.g_bf16) {
+                        uint2 o;
+                        o.x = pack_bf2(t.x, t.y);
+                        o.y = pack_bf2(t.z, t.w);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(d.g) + p * d.ldg + q) = o;
+                    } else {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.g) + p * d.ldg + q) = t;
+                    }
                 } else if (d.y_f32) {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.y) + p * d.ldy + q) = make_float4(v[0], v[1], v[2], v[3]);
                     if (want_stats) {
@@ -370,15 +398,15 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
     }
 }
 
-template <int BP, int BQ, int WP, int WQ, int PRO>
-int launch_pro(const dsaspp_conv_desc& d, hipStream_t s) {
+template <int BP, int BQ, int WP, int WQ, int PRO, int EPI>
+int launch_mode(const dsaspp_conv_desc& d, hipStream_t s) {
     const int64_t M64 = (int64_t)d.n_img * d.H * d.W;
     const int M = (int)M64;
     const int nP = (M + BP - 1) / BP, nQ = (d.cout + BQ - 1) / BQ;
     const int nblocks = nP * nQ;
     const size_t lds = (size_t)(BP + BQ) * BK * 2 + ((PRO != 0 && d.in_scale) ? (size_t)d.cin * 8 : 0);
     DS_REQUIRE(lds <= 160 * 1024, "conv_fwd: LDS request %zu too large", lds);
-    auto kern = conv_kernel<BP, BQ, WP, WQ, PRO>;
+    auto kern = conv_kernel<BP, BQ, WP, WQ, PRO, EPI>;
     if (lds > 64 * 1024) {
         static thread_local bool done = false;
         if (!done) {
@@ -393,10 +421,16 @@ int launch_pro(const dsaspp_conv_desc& d, hipStream_t s) {
 
 template <int BP, int BQ, int WP, int WQ>
 int launch(const dsaspp_conv_desc& d, hipStream_t s) {
-    if (d.in_mask) return launch_pro<BP, BQ, WP, WQ, 2>(d, s);
-    if (d.in_scale) return launch_pro<BP, BQ, WP, WQ, 1>(d, s);
-    if (d.in_relu) return launch_pro<BP, BQ, WP, WQ, 2>(d, s);
-    return launch_pro<BP, BQ, WP, WQ, 0>(d, s);
+    const int pro = d.in_mask ? 2 : d.in_scale ? 1 : d.in_relu ? 2 : 0;
+    const int epi = d.g ? 2 : ((d.epi_relu || d.s_acc) ? 1 : 0);
+    if (epi == 0) {
+        if (pro == 0) return launch_mode<BP, BQ, WP, WQ, 0, 0>(d, s);
+        if (pro == 1) return launch_mode<BP, BQ, WP, WQ, 1, 0>(d, s);
+        return launch_mode<BP, BQ, WP, WQ, 2, 0>(d, s);
+    }
+    DS_REQUIRE(pro == 0, "conv_fwd: the reference-masked and gradient-slab epilogues take a raw input (no prologue)");
+    if (epi == 1) return launch_mode<BP, BQ, WP, WQ, 0, 1>(d, s);
+    return launch_mode<BP, BQ, WP, WQ, 0, 2>(d, s);
 }
 
 }  // namespace
@@ -414,7 +448,7 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
     DS_REQUIRE(((uintptr_t)d.x & 15) == 0 && ((uintptr_t)d.w & 15) == 0, "conv_fwd: operands must be 16-byte aligned");
     DS_REQUIRE((d.in_scale == nullptr) == (d.in_shift == nullptr), "conv_fwd: in_scale/in_shift must come together");
     if (d.g) {
-        DS_REQUIRE(d.ldg % 4 == 0 && d.ldg >= d.cout && ((uintptr_t)d.g & 15) == 0, "conv_fwd: bad gradient slab stride/alignment");
+        DS_REQUIRE(d.ldg % 8 == 0 && d.ldg >= d.cout && ((uintptr_t)d.g & 15) == 0, "conv_fwd: bad gradient slab stride/alignment");
     } else {
         DS_REQUIRE(d.y != nullptr && d.ldy % 4 == 0 && d.ldy >= d.cout, "conv_fwd: bad output stride");
         DS_REQUIRE(((uintptr_t)d.y & 7) == 0, "conv_fwd: output must be 8-byte aligned");
@@ -428,6 +462,18 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
     if (d.out_mask) DS_REQUIRE(d.out_mask_ld % 4 == 0, "conv_fwd: out_mask_ld must be a multiple of 4");
 
     const int co = d.cout;
+    {   // experiment hook: DSASPP_CONV_TILE=<id> forces a tile for launches with cout > 64
+        static const int forced = [] { const char* e = getenv("DSASPP_CONV_TILE"); return e ? atoi(e) : 0; }();
+        if (forced && co > 64) {
+            switch (forced) {
+                case 1: return launch<128, 192, 2, 4>(d, s);
+                case 2: return launch<128, 128, 2, 4>(d, s);
+                case 5: return launch<64, 128, 1, 4>(d, s);
+                case 8: return launch<128, 64, 2, 2>(d, s);
+                default: break;
+            }
+        }
+    }
     if (co <= 32) return launch<128, 32, 4, 1>(d, s);
     if (co <= 48) return launch<256, 48, 4, 1>(d, s);
     if (co <= 64) return launch<128, 64, 2, 2>(d, s);

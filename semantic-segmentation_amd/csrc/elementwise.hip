@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void grad_extract_kernel(const dsaspp_gradx_de
     if (act) {
         for (int64_t m = (int64_t)blockIdx.y * RB + ry; m < d.M; m += (int64_t)gridDim.y * RB) {
             float v[8];
-            load8f(d.g + m * d.ldg + c, v);
+            if (d.g_bf16) unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(d.g) + m * d.ldg + c), v);
+            else load8f(reinterpret_cast<const float*>(d.g) + m * d.ldg + c, v);
             if (d.corr1) {
                 float x[8];
                 unpack8(*reinterpret_cast<const uint4*>(xs + m * d.ldxs + c), x);
@@ -478,7 +479,7 @@ extern "C" int dsaspp_bn_act(const dsaspp_bnact_desc* d, dsaspp_stream_t stream)
 }
 
 extern "C" int dsaspp_grad_extract(const dsaspp_gradx_desc* d, dsaspp_stream_t stream) {
-    DS_REQUIRE(d && d->M > 0 && d->C > 0 && d->C % 8 == 0 && d->ldg % 4 == 0 && d->lddz % 8 == 0, "grad_extract: bad descriptor");
+    DS_REQUIRE(d && d->M > 0 && d->C > 0 && d->C % 8 == 0 && d->ldg % 8 == 0 && d->lddz % 8 == 0, "grad_extract: bad descriptor");
     DS_REQUIRE(d->g && d->dz, "grad_extract: null tensor");
     if (d->corr1) DS_REQUIRE(d->corr2 && d->xs && d->s_mean && d->s_rstd && d->ldxs % 8 == 0, "grad_extract: correction inputs missing");
     if (d->relu || d->s_acc) DS_REQUIRE(d->yref && d->ldyref % 8 == 0, "grad_extract: yref missing");

@@ -137,6 +137,7 @@ class DenseASPP(nn.Module):
         for name, m in self.named_modules():
             if isinstance(m, nn.BatchNorm2d):
                 self.bn_modules[name] = m
+        self.grad_slab_dtype = torch.float32     # torch.bfloat16 halves gradient-slab traffic (see Engine)
         self._flat = None
         self._gflat = None
         self._w16 = None

@@ -58,7 +58,7 @@ class Slab:
         self.var = torch.ones(C, dtype=torch.float32, device=dev)
         self.rstd = torch.ones(C, dtype=torch.float32, device=dev)
         if train:
-            self.g = torch.zeros(M * C, dtype=torch.float32, device=dev)
+            self.g = torch.zeros(M * C, dtype=eng.grad_dtype, device=dev)
             self.corr = torch.zeros(2 * C, dtype=torch.float32, device=dev)   # corr1 | corr2
 
 
@@ -74,6 +74,10 @@ class Engine:
         self.backend = backend
         self.device = device
         self.R = backend.stat_replicas
+        # gradient slabs: bf16 halves the read-modify-write traffic of the slab-accumulating data
+        # gradients (what mixed-precision autograd does for the cat() gradient); fp32 is the exact option
+        self.grad_dtype = model.grad_slab_dtype if backend.act_dtype == torch.bfloat16 else torch.float32
+        self.g_bf16 = int(self.grad_dtype == torch.bfloat16)
         sp = self.spec
         dev = device
         f32, bf16 = torch.float32, backend.act_dtype
@@ -250,7 +254,7 @@ class Engine:
         conv = dict(in_scale=None, in_shift=None, in_relu=0, in_mask=None, in_mask_ld=0, bias=None,
                     out_mask=None, out_mask_ld=0, y=None, ldy=0, y_f32=0, stat_acc=None, epi_relu=0, ref=None,
                     ldref=0, e_scale=None, e_shift=None, e_mean=None, e_rstd=None, s_acc=None, g=None, ldg=0,
-                    g_accumulate=0)
+                    g_accumulate=0, g_bf16=self.g_bf16)
         self._conv_defaults = conv
 
         def C(**kw):
@@ -400,7 +404,7 @@ class Engine:
                    cols=0, dst_cols=0, accumulate=0)
 
         def gradx(**kw):
-            d = dict(hw=1, corr1=None, corr2=None, xs=None, ldxs=0, s_mean=None, s_rstd=None, mask=None, mask_ld=0,
+            d = dict(hw=1, g_bf16=self.g_bf16, corr1=None, corr2=None, xs=None, ldxs=0, s_mean=None, s_rstd=None, mask=None, mask_ld=0,
                      relu=0, yref=None, ldyref=0, r_scale=None, r_shift=None, r_mean=None, r_rstd=None, s_acc=None,
                      colsum=None, dz_f32=0)
             d.update(kw)

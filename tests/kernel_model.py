@@ -84,9 +84,8 @@ def op_conv(f):
         g = _view(f['g'], M, cout, f['ldg'])
         t = v * _vec(f['e_scale'], cout) if f['e_scale'] is not None else v
         if f['g_accumulate']:
-            g += t
-        else:
-            g.copy_(t)
+            t = g.to(torch.float32) + t
+        g.copy_(t.to(g.dtype))
     else:
         if f['y_f32']:
             y = _view(f['y'], M, cout, f['ldy'])
@@ -192,7 +191,7 @@ def op_bn_act(f):
 
 def op_grad_extract(f):
     M, C = f['M'], f['C']
-    v = _view(f['g'], M, C, f['ldg']).clone()
+    v = _view(f['g'], M, C, f['ldg']).to(torch.float32).clone()
     if f['corr1'] is not None:
         xs = _view(f['xs'], M, C, f['ldxs']).to(torch.float32)
         xhat = (xs - _vec(f['s_mean'], C)) * _vec(f['s_rstd'], C)

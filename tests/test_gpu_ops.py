@@ -11,7 +11,7 @@ R = 16
 
 def conv_fields(n, H, W, cin, cout, taps, dil, ldx=None, ldy=None, scale=True, relu=True, in_mask=False, bias=False,
                 out_mask=False, y_f32=False, stats=False, epi_relu=False, e_scale=False, s_acc=False, g=False,
-                g_acc=False, xoff=0, yoff=0, seed=0):
+                g_acc=False, g_bf16=False, xoff=0, yoff=0, seed=0):
     gen = torch.Generator().manual_seed(seed)
     M = n * H * W
     ldx = ldx or cin
@@ -21,7 +21,8 @@ def conv_fields(n, H, W, cin, cout, taps, dil, ldx=None, ldy=None, scale=True, r
     f = dict(n_img=n, H=H, W=W, cin=cin, cout=cout, taps=taps, dil=dil, x=Ref(x, xoff), ldx=ldx, w=Ref(w),
              in_scale=None, in_shift=None, in_relu=int(relu), in_mask=None, in_mask_ld=0, bias=None, out_mask=None,
              out_mask_ld=0, y=None, ldy=ldy, y_f32=int(y_f32), stat_acc=None, epi_relu=int(epi_relu), ref=None, ldref=0,
-             e_scale=None, e_shift=None, e_mean=None, e_rstd=None, s_acc=None, g=None, ldg=0, g_accumulate=int(g_acc))
+             e_scale=None, e_shift=None, e_mean=None, e_rstd=None, s_acc=None, g=None, ldg=0, g_accumulate=int(g_acc),
+             g_bf16=int(g_bf16))
     if scale:
         f['in_scale'] = Ref(torch.rand(cin, generator=gen) + 0.5)
         f['in_shift'] = Ref(torch.randn(cin, generator=gen) * 0.3)
@@ -44,7 +45,8 @@ def conv_fields(n, H, W, cin, cout, taps, dil, ldx=None, ldy=None, scale=True, r
         f['e_rstd'] = Ref(torch.rand(cout, generator=gen) + 0.5)
         f['s_acc'] = Ref(torch.zeros(R * 2 * cout))
     if g:
-        f['g'] = Ref(torch.randn(M * ldy + yoff, generator=gen), yoff)
+        gt = torch.randn(M * ldy + yoff, generator=gen)
+        f['g'] = Ref(bf(gt) if g_bf16 else gt, yoff)
         f['ldg'] = ldy
     else:
         f['y'] = Ref(torch.zeros(M * ldy + yoff, dtype=torch.float32 if y_f32 else torch.bfloat16), yoff)
@@ -75,6 +77,8 @@ CONV_CASES = [
     dict(n=2, H=10, W=12, cin=192, cout=336, taps=1, dil=1, scale=False, relu=False, epi_relu=True, e_scale=True,
          s_acc=True, g=True, g_acc=True, ldy=400, yoff=8),
     dict(n=1, H=8, W=16, cin=32, cout=256, taps=1, dil=1, scale=False, relu=False, out_mask=True, g=True),
+    dict(n=2, H=10, W=12, cin=192, cout=336, taps=1, dil=1, scale=False, relu=False, epi_relu=True, e_scale=True,
+         s_acc=True, g=True, g_acc=True, g_bf16=True, ldy=400, yoff=8),
     dict(n=1, H=16, W=16, cin=128, cout=64, taps=9, dil=24),
     dict(n=1, H=8, W=8, cin=160, cout=16, taps=1, dil=1, scale=False, relu=False, stats=True),
     dict(n=3, H=8, W=16, cin=256, cout=40, taps=9, dil=1, stats=True),
@@ -165,7 +169,8 @@ def test_rowwise(C):
     close(out['stat_acc'][0].view(R, -1).sum(0), out['stat_acc'][1].view(R, -1).sum(0), 1e-3, 'bn_act.stats')
     # grad_extract, all options
     for dz_f32 in (0, 1):
-        f = dict(M=M, C=C, hw=hw, g=Ref(torch.randn(M * ld, generator=gen)), ldg=ld, corr1=Ref(torch.randn(C, generator=gen) * 0.1),
+        gsrc = torch.randn(M * ld, generator=gen)
+        f = dict(M=M, C=C, hw=hw, g=Ref(bf(gsrc) if dz_f32 else gsrc), ldg=ld, g_bf16=dz_f32, corr1=Ref(torch.randn(C, generator=gen) * 0.1),
                  corr2=Ref(torch.randn(C, generator=gen) * 0.1), xs=Ref(bf(torch.randn(M * ld, generator=gen))), ldxs=ld,
                  s_mean=Ref(torch.randn(C, generator=gen) * 0.1), s_rstd=Ref(torch.rand(C, generator=gen) + 0.5),
                  mask=Ref((torch.rand(n * C, generator=gen) > 0.2).float() / 0.8), mask_ld=C, relu=1,

@@ -8,12 +8,14 @@ from semantic_segmentation_amd.backend import HipBackend
 from semantic_segmentation_amd.engine import Ref
 ap = argparse.ArgumentParser(); ap.add_argument('--batch', type=int, default=4); ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--only', default=''); ap.add_argument('--cin', type=int, default=1248)
-a = ap.parse_args()
+ap.add_argument('--tile', default=''); a = ap.parse_args()
+if a.tile: os.environ['DSASPP_CONV_TILE'] = a.tile
 dev = 'cuda'; be = HipBackend(); R = 16
 n, H, W = a.batch, 128, 256; M = n*H*W; LD = 2112; CIN = a.cin
 bf = torch.bfloat16
 slab = torch.randn(M*LD, device=dev).to(bf)
 g = torch.zeros(M*LD, device=dev)
+g16 = torch.zeros(M*LD, device=dev).to(bf)
 y1 = torch.randn(M*192, device=dev).to(bf)
 dz48 = torch.randn(M*48, device=dev).to(bf)
 dr = torch.zeros(M*192, device=dev)
@@ -25,7 +27,7 @@ mean, rstd = vec(LD, -0.5), vec(LD)
 acc = torch.zeros(R*2*LD, device=dev)
 dw1 = torch.zeros(192*CIN, device=dev); dw2 = torch.zeros(48*9*192, device=dev)
 base = dict(in_scale=None, in_shift=None, in_relu=0, in_mask=None, in_mask_ld=0, bias=None, out_mask=None, out_mask_ld=0, y=None, ldy=0,
-            y_f32=0, stat_acc=None, epi_relu=0, ref=None, ldref=0, e_scale=None, e_shift=None, e_mean=None, e_rstd=None, s_acc=None, g=None, ldg=0, g_accumulate=0)
+            y_f32=0, stat_acc=None, epi_relu=0, ref=None, ldref=0, e_scale=None, e_shift=None, e_mean=None, e_rstd=None, s_acc=None, g=None, ldg=0, g_accumulate=0, g_bf16=0)
 def conv(**kw):
     d = dict(base); d.update(kw); return ('conv', d)
 cases = {
@@ -33,6 +35,10 @@ cases = {
  'fwd3x3': conv(n_img=n, H=H, W=W, cin=192, cout=48, taps=9, dil=2, x=Ref(y1), ldx=192, w=Ref(w2), in_scale=Ref(sc2), in_shift=Ref(sh2), in_relu=1, y=Ref(slab, CIN), ldy=LD, stat_acc=Ref(acc)),
  'dgrad3x3': conv(n_img=n, H=H, W=W, cin=48, cout=192, taps=9, dil=2, x=Ref(dz48), ldx=48, w=Ref(w2t), y=Ref(dr), ldy=192, y_f32=1, epi_relu=1, ref=Ref(y1), ldref=192, e_scale=Ref(sc2), e_shift=Ref(sh2), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc)),
  'dgrad1x1_slab': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc), g=Ref(g), ldg=LD, g_accumulate=1),
+ 'dgrad1x1_slab16': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc), g=Ref(g16), ldg=LD, g_accumulate=1, g_bf16=1),
+ 'slab_noS': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), g=Ref(g), ldg=LD, g_accumulate=1),
+ 'slab_noS_noref': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), g=Ref(g), ldg=LD, g_accumulate=1),
+ 'slab_store_only': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), g=Ref(g), ldg=LD, g_accumulate=0),
  'wgrad1x1': ('wgrad', dict(n_img=n, H=H, W=W, cin=CIN, cout=192, taps=1, dil=1, x=Ref(slab), ldx=LD, in_scale=Ref(sc1), in_shift=Ref(sh1), in_relu=1, in_mask=None, in_mask_ld=0, dz=Ref(y1), lddz=192, dw=Ref(dw1), ksplit=0)),
  'wgrad3x3': ('wgrad', dict(n_img=n, H=H, W=W, cin=192, cout=48, taps=9, dil=2, x=Ref(y1), ldx=192, in_scale=Ref(sc2), in_shift=Ref(sh2), in_relu=1, in_mask=None, in_mask_ld=0, dz=Ref(dz48), lddz=48, dw=Ref(dw2), ksplit=0)),
 }
