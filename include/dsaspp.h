@@ -81,6 +81,16 @@ typedef struct dsaspp_conv_desc {
     int32_t ldg;
     int32_t g_accumulate;
     int32_t g_bf16;
+    int32_t s_ld;             /* row half-width of s_acc when it is a slice of a wider accumulator (0: cout) */
+    /* Extra sources (gradient-slab epilogue only, taps == 1): n_src in 2..4 sums the masked, scaled
+     * data gradients of several consumer layers of the same slab prefix in one pass,
+     *   g += sum_s e_scale_s * relu_mask_s(ref) * (x_s . w_s),
+     * so the slab is read and written once per group of layers instead of once per layer.  Source 0 is
+     * (x, w, e_scale, e_shift, s_acc, s_ld); sources 1..3 follow.  All sources share cin and ldx. */
+    int32_t n_src;
+    const void* x1; const void* w1; const float* es1; const float* eh1; float* sa1; int32_t sl1;
+    const void* x2; const void* w2; const float* es2; const float* eh2; float* sa2; int32_t sl2;
+    const void* x3; const void* w3; const float* es3; const float* eh3; float* sa3; int32_t sl3;
 } dsaspp_conv_desc;
 
 int dsaspp_conv_fwd(const dsaspp_conv_desc* d, dsaspp_stream_t stream);
@@ -155,7 +165,8 @@ int dsaspp_bn_finalize(const dsaspp_bn_desc* d, dsaspp_stream_t stream);
  */
 typedef struct dsaspp_bn_bwd_desc {
     int32_t C;
-    float* acc;               /* [R][2*C] */
+    float* acc;               /* [R][2*acc_ld], this call's channels at [r][c] and [r][acc_ld+c] */
+    int32_t acc_ld;           /* 0: C */
     float count;
     const float* scale;       /* forward scale (gamma*rstd) */
     const float* mean;

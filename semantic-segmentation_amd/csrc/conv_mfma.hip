@@ -86,13 +86,16 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
     const u16* wg = reinterpret_cast<const u16*>(d.w);
     const u16* w_ptr[WR];
     bool w_ok[WR];
+    auto w_setup = [&]() {
 #pragma unroll
-    for (int i = 0; i < WR; ++i) {
-        const int idx = tid + NT * i;
-        const int row = idx >> 3;
-        w_ok[i] = (idx < WCH) && (q_base + row < cout);
-        w_ptr[i] = wg + (w_ok[i] ? (int64_t)(q_base + row) * Ktot : 0);
-    }
+        for (int i = 0; i < WR; ++i) {
+            const int idx = tid + NT * i;
+            const int row = idx >> 3;
+            w_ok[i] = (idx < WCH) && (q_base + row < cout);
+            w_ptr[i] = wg + (w_ok[i] ? (int64_t)(q_base + row) * Ktot : 0);
+        }
+    };
+    w_setup();
 
     // per-tap row pointers (recomputed only when the tap changes)
     const u16* a_ptr[AR];
@@ -197,30 +200,133 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
 #pragma unroll
         for (int j = 0; j < MP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    tap_setup(0);
-    gload();
-    __syncthreads();   // scale/shift table visible
-    for (int s = 0; s < ksteps; ++s) {
-        sstore();                              // K-step s: registers -> LDS (prologue applied here)
-        __syncthreads();
-        if (s + 1 < ksteps) gload();           // K-step s+1 in flight while step s is multiplied
+    auto run_k = [&]() {
+        tap = 0;
+        c0 = 0;
+        tap_setup(0);
+        gload();
+        __syncthreads();   // scale/shift table visible
+        for (int s = 0; s < ksteps; ++s) {
+            sstore();                              // K-step s: registers -> LDS (prologue applied here)
+            __syncthreads();
+            if (s + 1 < ksteps) gload();           // K-step s+1 in flight while step s is multiplied
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int fo = ks ? frag_off1 : frag_off0;
-            bf16x8 af[MP], wf[MQ];
-#pragma unroll
-            for (int j = 0; j < MP; ++j)
-                af[j] = *reinterpret_cast<const bf16x8*>(As + (wp * TP + j * 16) * 128 + fo);
-#pragma unroll
-            for (int i = 0; i < MQ; ++i)
-                wf[i] = *reinterpret_cast<const bf16x8*>(Ws + (wq * TQ + i * 16) * 128 + fo);
-#pragma unroll
-            for (int i = 0; i < MQ; ++i)
+            for (int ks = 0; ks < 2; ++ks) {
+                const int fo = ks ? frag_off1 : frag_off0;
+                bf16x8 af[MP], wf[MQ];
 #pragma unroll
                 for (int j = 0; j < MP; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                    af[j] = *reinterpret_cast<const bf16x8*>(As + (wp * TP + j * 16) * 128 + fo);
+#pragma unroll
+                for (int i = 0; i < MQ; ++i)
+                    wf[i] = *reinterpret_cast<const bf16x8*>(Ws + (wq * TQ + i * 16) * 128 + fo);
+#pragma unroll
+                for (int i = 0; i < MQ; ++i)
+#pragma unroll
+                    for (int j = 0; j < MP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();                       // every wave is done reading before the next store
         }
-        __syncthreads();                       // every wave is done reading before the next store
+    };
+    const int rep = blockIdx.x % DS_R;
+
+    if (EPI != 3) {
+        run_k();
+    } else {
+        // Several consumer layers of the same slab prefix in one pass: each source's product is masked
+        // by that layer's ReLU, feeds that layer's BatchNorm-backward sums and is added, scaled, to a
+        // running total in accumulator layout; the slab is then read and written once for all of them.
+        float* sred = tab;                         // [2][BQ] block-level partial sums of one source
+        for (int c = tid; c < 2 * BQ; c += NT) sred[c] = 0.f;
+        uint2 rfm[MQ][MP];
+#pragma unroll
+        for (int i = 0; i < MQ; ++i)
+#pragma unroll
+            for (int j = 0; j < MP; ++j) {
+                const int q = q_base + wq * TQ + i * 16 + fc * 4;
+                const int64_t p = p_base + wp * TP + j * 16 + fr;
+                const bool ok = p < M && q < cout;
+                rfm[i][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(d.ref) + (ok ? p * d.ldref + q : 0));
+            }
+        f32x4 tot[MQ][MP];
+#pragma unroll
+        for (int i = 0; i < MQ; ++i)
+#pragma unroll
+            for (int j = 0; j < MP; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nsrc = d.n_src;
+        for (int sidx = 0; sidx < nsrc; ++sidx) {
+            const float *es, *eh;
+            float* sa;
+            int sl;
+            if (sidx == 0) { xg = reinterpret_cast<const u16*>(d.x); wg = reinterpret_cast<const u16*>(d.w); es = d.e_scale; eh = d.e_shift; sa = d.s_acc; sl = d.s_ld; }
+            else if (sidx == 1) { xg = reinterpret_cast<const u16*>(d.x1); wg = reinterpret_cast<const u16*>(d.w1); es = d.es1; eh = d.eh1; sa = d.sa1; sl = d.sl1; }
+            else if (sidx == 2) { xg = reinterpret_cast<const u16*>(d.x2); wg = reinterpret_cast<const u16*>(d.w2); es = d.es2; eh = d.eh2; sa = d.sa2; sl = d.sl2; }
+            else { xg = reinterpret_cast<const u16*>(d.x3); wg = reinterpret_cast<const u16*>(d.w3); es = d.es3; eh = d.eh3; sa = d.sa3; sl = d.sl3; }
+            if (sl <= 0) sl = cout;
+            w_setup();
+#pragma unroll
+            for (int i = 0; i < MQ; ++i)
+#pragma unroll
+                for (int j = 0; j < MP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            run_k();
+#pragma unroll
+            for (int i = 0; i < MQ; ++i) {
+                const int cl = wq * TQ + i * 16 + fc * 4;
+                const int q = q_base + cl;
+                const bool qok = q < cout;
+                const int qc = qok ? q : 0;
+                const float4 e_s = *reinterpret_cast<const float4*>(es + qc);
+                const float4 e_h = *reinterpret_cast<const float4*>(eh + qc);
+                const float4 e_m = *reinterpret_cast<const float4*>(d.e_mean + qc);
+                const float4 e_r = *reinterpret_cast<const float4*>(d.e_rstd + qc);
+                const float sc4[4] = {e_s.x, e_s.y, e_s.z, e_s.w}, sh4[4] = {e_h.x, e_h.y, e_h.z, e_h.w};
+                const float mu4[4] = {e_m.x, e_m.y, e_m.z, e_m.w}, rs4[4] = {e_r.x, e_r.y, e_r.z, e_r.w};
+                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < MP; ++j) {
+                    const uint2 rr = rfm[i][j];
+                    const float rf[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pre = fmaf(rf[e], sc4[e], sh4[e]);
+                        const float v = (pre > 0.f) ? acc[i][j][e] : 0.f;   // rows past M and channels past cout are exact zeros
+                        s1[e] += v;
+                        s2[e] += v * ((rf[e] - mu4[e]) * rs4[e]);
+                        tot[i][j][e] = fmaf(v, sc4[e], tot[i][j][e]);
+                    }
+                }
+                if (sa) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) {
+                            s1[e] += __shfl_xor(s1[e], o, 64);
+                            s2[e] += __shfl_xor(s2[e], o, 64);
+                        }
+                    }
+                    if (fr == 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            atomicAdd(sred + cl + e, s1[e]);
+                            atomicAdd(sred + BQ + cl + e, s2[e]);
+                        }
+                    }
+                }
+            }
+            if (sa) {
+                __syncthreads();
+                for (int c = tid; c < 2 * BQ; c += NT) {
+                    const int half = c / BQ, cc = c - half * BQ;
+                    if (q_base + cc < cout) atomicAdd(sa + (size_t)rep * 2 * sl + half * sl + q_base + cc, sred[c]);
+                    sred[c] = 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MQ; ++i)
+#pragma unroll
+            for (int j = 0; j < MP; ++j) acc[i][j] = tot[i][j];
     }
 
     // ---- epilogue.  The accumulators hold 4 consecutive channels of one pixel per lane; going
@@ -237,16 +343,15 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
     static_assert(NW * 16 * ROWF * 4 + 5 * BQ * 4 <= A_BYTES + W_BYTES, "epilogue LDS fits in the staging buffers");
     float* stage = reinterpret_cast<float*>(smem) + wave * (16 * ROWF);
     float* epar = reinterpret_cast<float*>(smem) + NW * 16 * ROWF;     // [5][BQ]: bias, scale, shift, mean, rstd
-    const int rep = blockIdx.x % DS_R;
-    const bool want_stats = (EPI != 2) && (d.stat_acc != nullptr);
-    const bool want_s = (EPI != 0) && d.s_acc != nullptr;
-    const bool need_ref = (EPI != 0) && (d.epi_relu || want_s);
-    const bool acc_g = (EPI == 2) && d.g_accumulate;
+    const bool want_stats = (EPI < 2) && (d.stat_acc != nullptr);
+    const bool want_s = (EPI == 1 || EPI == 2) && d.s_acc != nullptr;
+    const bool need_ref = (EPI == 1 || EPI == 2) && (d.epi_relu || want_s);
+    const bool acc_g = (EPI >= 2) && d.g_accumulate;
     for (int c = tid; c < BQ; c += NT) {
         const int q = q_base + c;
         const bool ok = q < cout;
         epar[c] = (ok && d.bias) ? d.bias[q] : 0.f;
-        epar[BQ + c] = (ok && d.e_scale) ? d.e_scale[q] : 1.f;
+        epar[BQ + c] = (ok && d.e_scale && EPI != 3) ? d.e_scale[q] : 1.f;
         epar[2 * BQ + c] = (ok && d.e_scale) ? d.e_shift[q] : 0.f;
         epar[3 * BQ + c] = (ok && want_s) ? d.e_mean[q] : 0.f;
         epar[4 * BQ + c] = (ok && want_s) ? d.e_rstd[q] : 1.f;
@@ -264,8 +369,8 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
     // instead of one per 16-pixel group
     constexpr int NI = NCB * NRP;
     bool ok_[MP][NI];
-    float4 gold_[(EPI == 2) ? MP : 1][NI];
-    uint2 rr_[(EPI != 0) ? MP : 1][NI];
+    float4 gold_[(EPI >= 2) ? MP : 1][NI];
+    uint2 rr_[(EPI == 1 || EPI == 2) ? MP : 1][NI];
 #pragma unroll
     for (int j = 0; j < MP; ++j) {
 #pragma unroll
@@ -279,8 +384,8 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
                 ok_[j][it] = ok;
                 const int64_t pc = ok ? p : 0;
                 const int qc = ok ? q : 0;
-                if (EPI != 0 && need_ref) rr_[j][it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(d.ref) + pc * d.ldref + qc);
-                if (EPI == 2 && acc_g) {
+                if ((EPI == 1 || EPI == 2) && need_ref) rr_[j][it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(d.ref) + pc * d.ldref + qc);
+                if (EPI >= 2 && acc_g) {
                     if (d.g_bf16) {
                         const uint2 gb = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(d.g) + pc * d.ldg + qc);
                         gold_[j][it] = make_float4(bf_lo(gb.x), bf_hi(gb.x), bf_lo(gb.y), bf_hi(gb.y));
@@ -323,25 +428,25 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
                     v[0] *= mk.x; v[1] *= mk.y; v[2] *= mk.z; v[3] *= mk.w;
                 }
                 float rf[4] = {0, 0, 0, 0};
-                if (EPI != 0 && need_ref) {
+                if ((EPI == 1 || EPI == 2) && need_ref) {
                     const uint2 rr = rr_[j][it];
                     rf[0] = bf_lo(rr.x); rf[1] = bf_hi(rr.x); rf[2] = bf_lo(rr.y); rf[3] = bf_hi(rr.y);
                 }
-                if (EPI != 0 && d.epi_relu) {
+                if ((EPI == 1 || EPI == 2) && d.epi_relu) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float pre = d.e_scale ? fmaf(rf[e], epar[BQ + cl + e], epar[2 * BQ + cl + e]) : rf[e];
                         if (!(pre > 0.f)) v[e] = 0.f;
                     }
                 }
-                if (EPI != 0 && want_s) {
+                if ((EPI == 1 || EPI == 2) && want_s) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         st_a[cb][e] += v[e];
                         st_b[cb][e] += v[e] * ((rf[e] - epar[3 * BQ + cl + e]) * epar[4 * BQ + cl + e]);
                     }
                 }
-                if (EPI == 2) {
+                if (EPI >= 2) {
                     float4 t = make_float4(v[0] * epar[BQ + cl], v[1] * epar[BQ + cl + 1], v[2] * epar[BQ + cl + 2],
                                            v[3] * epar[BQ + cl + 3]);
                     if (acc_g) { t.x += gold_[j][it].x; t.y += gold_[j][it].y; t.z += gold_[j][it].z; t.w += gold_[j][it].w; }
@@ -374,7 +479,8 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
         }
     }
     if (want_stats || want_s) {
-        float* base = (want_s ? d.s_acc : d.stat_acc) + (size_t)rep * 2 * cout;
+        const int sld = (want_s && d.s_ld > 0) ? d.s_ld : cout;
+        float* base = (want_s ? d.s_acc : d.stat_acc) + (size_t)rep * 2 * sld;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
@@ -391,7 +497,7 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     atomicAdd(base + q + e, st_a[cb][e]);
-                    atomicAdd(base + cout + q + e, st_b[cb][e]);
+                    atomicAdd(base + sld + q + e, st_b[cb][e]);
                 }
             }
         }
@@ -404,7 +510,7 @@ int launch_mode(const dsaspp_conv_desc& d, hipStream_t s) {
     const int M = (int)M64;
     const int nP = (M + BP - 1) / BP, nQ = (d.cout + BQ - 1) / BQ;
     const int nblocks = nP * nQ;
-    const size_t lds = (size_t)(BP + BQ) * BK * 2 + ((PRO != 0 && d.in_scale) ? (size_t)d.cin * 8 : 0);
+    const size_t lds = (size_t)(BP + BQ) * BK * 2 + ((PRO != 0 && d.in_scale) ? (size_t)d.cin * 8 : 0) + (EPI == 3 ? (size_t)BQ * 8 : 0);
     DS_REQUIRE(lds <= 160 * 1024, "conv_fwd: LDS request %zu too large", lds);
     auto kern = conv_kernel<BP, BQ, WP, WQ, PRO, EPI>;
     if (lds > 64 * 1024) {
@@ -432,6 +538,8 @@ int launch(const dsaspp_conv_desc& d, hipStream_t s) {
     if (epi == 1) return launch_mode<BP, BQ, WP, WQ, 0, 1>(d, s);
     return launch_mode<BP, BQ, WP, WQ, 0, 2>(d, s);
 }
+
+int launch_multi(const dsaspp_conv_desc& d, hipStream_t s) { return launch_mode<128, 128, 2, 4, 0, 3>(d, s); }
 
 }  // namespace
 
@@ -461,6 +569,16 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
     if (d.in_mask) DS_REQUIRE(d.in_mask_ld % 4 == 0, "conv_fwd: in_mask_ld must be a multiple of 4");
     if (d.out_mask) DS_REQUIRE(d.out_mask_ld % 4 == 0, "conv_fwd: out_mask_ld must be a multiple of 4");
 
+    if (d.n_src > 1) {
+        DS_REQUIRE(d.n_src <= 4, "conv_fwd: at most 4 sources (got %d)", d.n_src);
+        DS_REQUIRE(d.g && d.epi_relu && d.taps == 1 && d.ref && d.e_scale && d.e_shift && d.e_mean && d.e_rstd && !d.in_scale && !d.in_mask && !d.in_relu && !d.bias && !d.out_mask,
+                   "conv_fwd: several sources need the 1x1 gradient-slab form (g, ref, e_scale/e_shift, e_mean/e_rstd, raw inputs)");
+        DS_REQUIRE(d.x1 && d.w1 && d.es1 && d.eh1 && (d.n_src < 3 || (d.x2 && d.w2 && d.es2 && d.eh2)) && (d.n_src < 4 || (d.x3 && d.w3 && d.es3 && d.eh3)),
+                   "conv_fwd: null operand in an extra source");
+        DS_REQUIRE((((uintptr_t)d.x1 | (uintptr_t)d.w1 | (uintptr_t)d.x2 | (uintptr_t)d.w2 | (uintptr_t)d.x3 | (uintptr_t)d.w3) & 15) == 0,
+                   "conv_fwd: operands must be 16-byte aligned");
+        return launch_multi(d, s);
+    }
     const int co = d.cout;
     {   // experiment hook: DSASPP_CONV_TILE=<id> forces a tile for launches with cout > 64
         static const int forced = [] { const char* e = getenv("DSASPP_CONV_TILE"); return e ? atoi(e) : 0; }();

@@ -55,12 +55,13 @@ __global__ void bn_bwd_finalize_kernel(const dsaspp_bn_bwd_desc d) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.C) return;
     float s1 = 0.f, s2 = 0.f;
+    const int ald = d.acc_ld > 0 ? d.acc_ld : d.C;
     for (int r = 0; r < DS_R; ++r) {
-        float* row = d.acc + (size_t)r * 2 * d.C;
+        float* row = d.acc + (size_t)r * 2 * ald;
         s1 += row[c];
-        s2 += row[d.C + c];
+        s2 += row[ald + c];
         row[c] = 0.f;
-        row[d.C + c] = 0.f;
+        row[ald + c] = 0.f;
     }
     if (d.dbeta) d.dbeta[c] += s1;
     if (d.dgamma) d.dgamma[c] += s2;

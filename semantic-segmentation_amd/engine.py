@@ -183,6 +183,9 @@ class Engine:
             self.tmp_a = zeros(big, bf16)
             self.tmp_b = zeros(big)          # fp32: input of the BatchNorm backward (see bn_bwd_apply)
             self.tmp_c = zeros(big, bf16)
+            # bottleneck gradients of the layers whose slab data gradients are applied together
+            self.dgrad_group = max(1, min(4, int(getattr(model, 'dgrad_group', 1))))
+            self.dy1_bufs = [self.tmp_c] + [zeros(max(self.M1, self.M2) * cmax_mid, bf16) for _ in range(self.dgrad_group - 1)]
             self.coef = zeros(3 * max(sp.c_feat, cmax_mid, sp.c_stem))
             self.dw0pad = zeros(sp.c_stem * S.STEM_KPAD)
             n_drop = 5 * sp.d1 + sp.C_aspp
@@ -427,6 +430,13 @@ class Engine:
                 f.update(corr1=_r(slab.corr, slab_off), corr2=_r(slab.corr, slab.C + slab_off))
             ops.op('bn_bwd_finalize', **f)
 
+        def bn_bwd_slice(name, Cfull, acc, count, slab, c0, cn):
+            """BatchNorm backward bookkeeping of channels [c0, c0+cn) of a slab-input BatchNorm."""
+            ops.op('bn_bwd_finalize', C=cn, acc=_r(self.acc[acc], c0), acc_ld=Cfull, count=float(count),
+                   scale=self.bnt(name, 'scale', Cfull, c0), dgamma=self.PG(name + '.weight') + c0,
+                   dbeta=self.PG(name + '.bias') + c0, mode=1, coefA=None, coefB=None, coefC=None,
+                   corr1=_r(slab.corr, c0), corr2=_r(slab.corr, slab.C + c0), mean=None, rstd=None)
+
         def bn_apply(C_, M_, dr, y, dy, colsum=None):
             ops.op('bn_bwd_apply', M=M_, C=C_, dr=_r(dr), lddr=C_, dr_f32=1, y=_r(y), ldy=C_, coefA=_r(self.coef, 0),
                    coefB=_r(self.coef, C_), coefC=_r(self.coef, 2 * C_), dy=_r(dy), lddy=C_, colsum=colsum)
@@ -511,28 +521,56 @@ class Engine:
               e_rstd=_r(slab.rstd), s_acc=_r(self.acc[blk.trans_prefix + '.s']), g=_r(slab.g), ldg=slab.C,
               g_accumulate=0)
             bn_bwd(nt, blk.C, blk.trans_prefix + '.s', M, 1, slab=slab, slab_off=0)
-            for l in reversed(blk.layers):
-                n1, n2 = l.prefix + '.norm1', l.prefix + '.norm2'
-                y1 = self.y1[l.prefix]
-                slab_extract(slab, l.cin, l.growth, dz)
-                WG(n_img=B, H=H, W=W, cin=l.mid, cout=l.growth, taps=9, dil=l.dil, x=_r(y1), ldx=l.mid,
-                   in_scale=self.bnt(n2, 'scale', l.mid), in_shift=self.bnt(n2, 'shift', l.mid), in_relu=1, dz=_r(dz),
-                   lddz=l.growth, dw=self.PG(l.prefix + '.conv2.weight'))
-                C(n_img=B, H=H, W=W, cin=l.growth, cout=l.mid, taps=9, dil=l.dil, x=_r(dz), ldx=l.growth,
-                  w=self.WT16(l.prefix + '.conv2.weight'), y=_r(dr), ldy=l.mid, y_f32=1, epi_relu=1, ref=_r(y1), ldref=l.mid,
-                  e_scale=self.bnt(n2, 'scale', l.mid), e_shift=self.bnt(n2, 'shift', l.mid),
-                  e_mean=self.bnt(n2, 'mean', l.mid), e_rstd=self.bnt(n2, 'rstd', l.mid),
-                  s_acc=_r(self.acc[l.prefix + '.s2']))
-                bn_bwd(n2, l.mid, l.prefix + '.s2', M, 0)
-                bn_apply(l.mid, M, dr, y1, dy1)
-                WG(n_img=B, H=H, W=W, cin=l.cin, cout=l.mid, taps=1, dil=1, x=_r(slab.x), ldx=slab.C,
-                   in_scale=self.bnt(n1, 'scale', l.cin), in_shift=self.bnt(n1, 'shift', l.cin), in_relu=1, dz=_r(dy1),
-                   lddz=l.mid, dw=self.PG(l.prefix + '.conv1.weight'))
-                C(n_img=B, H=H, W=W, cin=l.mid, cout=l.cin, taps=1, dil=1, x=_r(dy1), ldx=l.mid,
-                  w=self.WT16(l.prefix + '.conv1.weight'), epi_relu=1, ref=_r(slab.x), ldref=slab.C,
-                  e_scale=self.bnt(n1, 'scale', l.cin), e_shift=self.bnt(n1, 'shift', l.cin), e_mean=_r(slab.mean),
-                  e_rstd=_r(slab.rstd), s_acc=_r(self.acc[l.prefix + '.s1']), g=_r(slab.g), ldg=slab.C, g_accumulate=1)
-                bn_bwd(n1, l.cin, l.prefix + '.s1', M, 1, slab=slab, slab_off=0)
+            # Layers are taken in groups, last layer first.  Within a group only the narrow channel
+            # range the group itself produced is updated layer by layer; the wide slab prefix below it,
+            # which every layer of the group feeds, is read and written once by a single multi-source
+            # data-gradient launch after the group's bottleneck gradients exist.
+            rev = list(reversed(blk.layers))
+            gi = 0
+            while gi < len(rev):
+                grp = rev[gi:gi + self.dgrad_group]
+                if any(l.mid != grp[0].mid for l in grp):
+                    grp = grp[:1]
+                gi += len(grp)
+                c_lo = grp[-1].cin
+                for k, l in enumerate(grp):
+                    n1, n2 = l.prefix + '.norm1', l.prefix + '.norm2'
+                    y1 = self.y1[l.prefix]
+                    dy1k = self.dy1_bufs[k]
+                    slab_extract(slab, l.cin, l.growth, dz)
+                    WG(n_img=B, H=H, W=W, cin=l.mid, cout=l.growth, taps=9, dil=l.dil, x=_r(y1), ldx=l.mid,
+                       in_scale=self.bnt(n2, 'scale', l.mid), in_shift=self.bnt(n2, 'shift', l.mid), in_relu=1, dz=_r(dz),
+                       lddz=l.growth, dw=self.PG(l.prefix + '.conv2.weight'))
+                    C(n_img=B, H=H, W=W, cin=l.growth, cout=l.mid, taps=9, dil=l.dil, x=_r(dz), ldx=l.growth,
+                      w=self.WT16(l.prefix + '.conv2.weight'), y=_r(dr), ldy=l.mid, y_f32=1, epi_relu=1, ref=_r(y1), ldref=l.mid,
+                      e_scale=self.bnt(n2, 'scale', l.mid), e_shift=self.bnt(n2, 'shift', l.mid),
+                      e_mean=self.bnt(n2, 'mean', l.mid), e_rstd=self.bnt(n2, 'rstd', l.mid),
+                      s_acc=_r(self.acc[l.prefix + '.s2']))
+                    bn_bwd(n2, l.mid, l.prefix + '.s2', M, 0)
+                    bn_apply(l.mid, M, dr, y1, dy1k)
+                    WG(n_img=B, H=H, W=W, cin=l.cin, cout=l.mid, taps=1, dil=1, x=_r(slab.x), ldx=slab.C,
+                       in_scale=self.bnt(n1, 'scale', l.cin), in_shift=self.bnt(n1, 'shift', l.cin), in_relu=1, dz=_r(dy1k),
+                       lddz=l.mid, dw=self.PG(l.prefix + '.conv1.weight'))
+                    cn = l.cin - c_lo
+                    if cn > 0:     # channels produced by the later-processed layers of this group
+                        C(n_img=B, H=H, W=W, cin=l.mid, cout=cn, taps=1, dil=1, x=_r(dy1k), ldx=l.mid,
+                          w=self.WT16(l.prefix + '.conv1.weight') + c_lo * l.mid, epi_relu=1, ref=_r(slab.x, c_lo),
+                          ldref=slab.C, e_scale=self.bnt(n1, 'scale', l.cin, c_lo), e_shift=self.bnt(n1, 'shift', l.cin, c_lo),
+                          e_mean=_r(slab.mean, c_lo), e_rstd=_r(slab.rstd, c_lo), s_acc=_r(self.acc[l.prefix + '.s1'], c_lo),
+                          s_ld=l.cin, g=_r(slab.g, c_lo), ldg=slab.C, g_accumulate=1)
+                        bn_bwd_slice(n1, l.cin, l.prefix + '.s1', M, slab, c_lo, cn)
+                multi = dict(n_src=len(grp))
+                for k, l in enumerate(grp):
+                    n1 = l.prefix + '.norm1'
+                    src = (_r(self.dy1_bufs[k]), self.WT16(l.prefix + '.conv1.weight'), self.bnt(n1, 'scale', l.cin),
+                           self.bnt(n1, 'shift', l.cin), _r(self.acc[l.prefix + '.s1']), l.cin)
+                    names = ('x', 'w', 'e_scale', 'e_shift', 's_acc', 's_ld') if k == 0 else \
+                        tuple(n + str(k) for n in ('x', 'w', 'es', 'eh', 'sa', 'sl'))
+                    multi.update(zip(names, src))
+                C(n_img=B, H=H, W=W, cin=grp[0].mid, cout=c_lo, taps=1, dil=1, ldx=grp[0].mid, epi_relu=1, ref=_r(slab.x),
+                  ldref=slab.C, e_mean=_r(slab.mean), e_rstd=_r(slab.rstd), g=_r(slab.g), ldg=slab.C, g_accumulate=1, **multi)
+                for l in grp:
+                    bn_bwd_slice(l.prefix + '.norm1', l.cin, l.prefix + '.s1', M, slab, 0, c_lo)
 
         # ---- stem: maxpool + ReLU + norm0 backward, conv0 weight gradient
         cs = sp.c_stem

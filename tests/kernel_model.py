@@ -77,12 +77,25 @@ def op_conv(f):
         v = torch.where(pre > 0, v, torch.zeros_like(v))
     if f['s_acc'] is not None:
         xhat = (ref - _vec(f['e_mean'], cout)) * _vec(f['e_rstd'], cout)
-        acc2 = _view(f['s_acc'], R, 2 * cout, 2 * cout)
+        sld = f.get('s_ld', 0) or cout
+        acc2 = _view(f['s_acc'], R, sld + cout, 2 * sld)
         acc2[0, :cout] += v.sum(0)
-        acc2[0, cout:] += (v * xhat).sum(0)
+        acc2[0, sld:sld + cout] += (v * xhat).sum(0)
     if f['g'] is not None:
         g = _view(f['g'], M, cout, f['ldg'])
         t = v * _vec(f['e_scale'], cout) if f['e_scale'] is not None else v
+        for k in range(1, f.get('n_src', 0) or 1):
+            xs = _view(f['x%d' % k], M, cin, f['ldx']).to(torch.float32)
+            ws = _view(f['w%d' % k], cout, cin, cin).to(torch.float32)
+            vs = xs @ ws.t()
+            pre = ref * _vec(f['es%d' % k], cout) + _vec(f['eh%d' % k], cout)
+            vs = torch.where(pre > 0, vs, torch.zeros_like(vs))
+            if f['sa%d' % k] is not None:
+                sld = f['sl%d' % k] or cout
+                acck = _view(f['sa%d' % k], R, sld + cout, 2 * sld)
+                acck[0, :cout] += vs.sum(0)
+                acck[0, sld:sld + cout] += (vs * xhat).sum(0)
+            t = t + vs * _vec(f['es%d' % k], cout)
         if f['g_accumulate']:
             t = g.to(torch.float32) + t
         g.copy_(t.to(g.dtype))
@@ -154,9 +167,11 @@ def op_bn_finalize(f):
 
 def op_bn_bwd_finalize(f):
     C = f['C']
-    acc = _view(f['acc'], R, 2 * C, 2 * C)
-    s1, s2 = acc[:, :C].sum(0), acc[:, C:].sum(0)
-    acc.zero_()
+    ald = f.get('acc_ld', 0) or C
+    acc = _view(f['acc'], R, ald + C, 2 * ald)
+    s1, s2 = acc[:, :C].sum(0), acc[:, ald:ald + C].sum(0)
+    acc[:, :C] = 0
+    acc[:, ald:ald + C] = 0
     if f['dbeta'] is not None:
         _vec(f['dbeta'], C).add_(s1)
     if f['dgamma'] is not None:

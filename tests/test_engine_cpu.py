@@ -48,6 +48,25 @@ def test_train_step_fp32(fp32_model):
         assert float((br[n].float() - b.float()).abs().max()) < 1e-4, n
 
 
+@pytest.mark.parametrize('group', [1, 3, 4])
+def test_grouped_dense_backward_fp32(fp32_model, group):
+    """Blocks of 6, 4, 2 and 3 layers: full groups, remainder groups and single-layer groups of the
+    grouped slab data gradient all reproduce the oracle's gradients."""
+    cfg = dict(TINY_CFG)
+    cfg['block_config'] = (6, 4, 2, 3)
+    ref, mod = make_pair(cfg)
+    mod.dgrad_group = group
+    mod.set_backend(kernel_model.ModelBackend())
+    x, labels = make_batch(1, 32, 48)
+    masks = make_dropout_masks(ref, 1, torch.Generator().manual_seed(7))
+    loss_r, g_ref = oracle_train(ref, x, labels, masks)
+    mod.train()
+    loss_m = mod.train_step(x, labels, dropout_masks=masks)
+    assert abs(float(loss_r) - float(loss_m)) < 1e-5
+    rel, cos, worst = grad_report(g_ref, {n: p.grad for n, p in mod.named_parameters()})
+    assert rel < 1e-3 and cos > 0.99999, (rel, cos, worst)
+
+
 def test_autograd_path_matches_fused_path(fp32_model):
     """model(x) -> CrossEntropyLoss -> backward (the reference's loop, graph_seg_main.py:237-239)."""
     ref, mod = make_pair(TINY_CFG)

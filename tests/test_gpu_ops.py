@@ -90,6 +90,46 @@ def test_conv(case):
     check_conv(conv_fields(seed=case, **CONV_CASES[case]))
 
 
+@pytest.mark.parametrize('n_src', [2, 3, 4])
+def test_conv_multi_source(n_src):
+    """Several consumer layers' 1x1 data gradients summed into the gradient slab in one pass, each with its
+    own ReLU mask, scale and BatchNorm-backward sums (written into a slice of a wider accumulator)."""
+    cout, cin, sld = 200, 192, 264
+    f = conv_fields(n=2, H=10, W=12, cin=cin, cout=cout, taps=1, dil=1, scale=False, relu=False, epi_relu=True,
+                    e_scale=True, s_acc=True, g=True, g_acc=True, ldy=400, yoff=8, seed=40 + n_src)
+    gen = torch.Generator().manual_seed(50 + n_src)
+    M = 2 * 10 * 12
+    f['s_acc'] = Ref(torch.zeros(R * 2 * sld + 16), 16)
+    f['s_ld'] = sld
+    f['n_src'] = n_src
+    for k in range(1, 4):
+        on = k < n_src
+        f['x%d' % k] = Ref(bf(torch.randn(M * cin, generator=gen))) if on else None
+        f['w%d' % k] = Ref(bf(torch.randn(cout * cin, generator=gen) * cin ** -0.5)) if on else None
+        f['es%d' % k] = Ref(torch.rand(cout, generator=gen) + 0.5) if on else None
+        f['eh%d' % k] = Ref(torch.randn(cout, generator=gen) * 0.3) if on else None
+        f['sa%d' % k] = Ref(torch.zeros(R * 2 * (sld + 8 * k))) if on else None
+        f['sl%d' % k] = sld + 8 * k if on else 0
+    out = run_both('conv', f)
+    close(out['g'][0], out['g'][1], 2e-2, 'conv_multi.g')
+    c, g = out['s_acc']
+    close(c[16:].view(R, -1).sum(0), g[16:].view(R, -1).sum(0), 2e-2, 'conv_multi.s_acc')
+    for k in range(1, n_src):
+        c, g = out['sa%d' % k]
+        close(c.view(R, -1).sum(0), g.view(R, -1).sum(0), 2e-2, 'conv_multi.sa%d' % k)
+
+
+def test_conv_s_slice():
+    f = conv_fields(n=2, H=10, W=12, cin=192, cout=96, taps=1, dil=1, scale=False, relu=False, epi_relu=True,
+                    e_scale=True, s_acc=True, g=True, g_acc=True, ldy=400, yoff=8, seed=77)
+    f['s_acc'] = Ref(torch.zeros(R * 2 * 160 + 32), 32)
+    f['s_ld'] = 160
+    out = run_both('conv', f)
+    close(out['g'][0], out['g'][1], 2e-2, 'conv_slice.g')
+    c, g = out['s_acc']
+    close(c[32:].view(R, -1).sum(0), g[32:].view(R, -1).sum(0), 2e-2, 'conv_slice.s_acc')
+
+
 def wgrad_fields(n, H, W, cin, cout, taps, dil, ldx=None, lddz=None, scale=True, relu=True, in_mask=False, seed=0,
                  ksplit=0):
     gen = torch.Generator().manual_seed(100 + seed)
@@ -152,6 +192,16 @@ def test_bn_finalize_and_bwd():
         out = run_both('bn_bwd_finalize', fb)
         for k, (c, g) in out.items():
             close(c, g, 1e-5, 'bn_bwd_finalize.' + k)
+    # a channel sub-range of a wider accumulator: only that range is consumed and cleared
+    Cw, cs, cn2 = 96, 16, 40
+    fb = dict(C=cn2, acc=Ref(torch.randn(R * 2 * Cw, generator=gen), cs), acc_ld=Cw, count=777.0,
+              scale=Ref(torch.rand(cn2, generator=gen)), mean=Ref(torch.randn(cn2, generator=gen)),
+              rstd=Ref(torch.rand(cn2, generator=gen) + 0.5), dgamma=Ref(torch.randn(cn2, generator=gen)),
+              dbeta=Ref(torch.randn(cn2, generator=gen)), mode=1, coefA=None, coefB=None, coefC=None,
+              corr1=Ref(torch.randn(cn2, generator=gen)), corr2=Ref(torch.randn(cn2, generator=gen)))
+    out = run_both('bn_bwd_finalize', fb)
+    for k, (c, g) in out.items():
+        close(c, g, 1e-5, 'bn_bwd_finalize(slice).' + k)
 
 
 @pytest.mark.parametrize('C', [48, 200])

@@ -18,6 +18,8 @@ g = torch.zeros(M*LD, device=dev)
 g16 = torch.zeros(M*LD, device=dev).to(bf)
 y1 = torch.randn(M*192, device=dev).to(bf)
 dz48 = torch.randn(M*48, device=dev).to(bf)
+y1b, y1c, y1d = (torch.randn(M*192, device=dev).to(bf) for _ in range(3))
+acc1, acc2, acc3 = (torch.zeros(R*2*LD, device=dev) for _ in range(3))
 dr = torch.zeros(M*192, device=dev)
 def vec(c, lo=0.5): return torch.rand(c, device=dev) + lo
 w1 = (torch.randn(192*CIN, device=dev)*0.03).to(bf); w1t = (torch.randn(192*CIN, device=dev)*0.03).to(bf)
@@ -39,6 +41,12 @@ cases = {
  'slab_noS': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), g=Ref(g), ldg=LD, g_accumulate=1),
  'slab_noS_noref': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), g=Ref(g), ldg=LD, g_accumulate=1),
  'slab_store_only': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), g=Ref(g), ldg=LD, g_accumulate=0),
+ 'slab_multi4': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc), g=Ref(g), ldg=LD, g_accumulate=1,
+                     n_src=4, x1=Ref(y1b), w1=Ref(w1t), es1=Ref(sc1), eh1=Ref(sh1), sa1=Ref(acc1), x2=Ref(y1c), w2=Ref(w1t), es2=Ref(sc1), eh2=Ref(sh1), sa2=Ref(acc2), x3=Ref(y1d), w3=Ref(w1t), es3=Ref(sc1), eh3=Ref(sh1), sa3=Ref(acc3)),
+ 'slab_multi4_noS': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), e_mean=Ref(mean), e_rstd=Ref(rstd), g=Ref(g), ldg=LD, g_accumulate=1,
+                     n_src=4, x1=Ref(y1b), w1=Ref(w1t), es1=Ref(sc1), eh1=Ref(sh1), x2=Ref(y1c), w2=Ref(w1t), es2=Ref(sc1), eh2=Ref(sh1), x3=Ref(y1d), w3=Ref(w1t), es3=Ref(sc1), eh3=Ref(sh1)),
+ 'slab_multi2': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc), g=Ref(g), ldg=LD, g_accumulate=1,
+                     n_src=2, x1=Ref(y1b), w1=Ref(w1t), es1=Ref(sc1), eh1=Ref(sh1), sa1=Ref(acc1)),
  'wgrad1x1': ('wgrad', dict(n_img=n, H=H, W=W, cin=CIN, cout=192, taps=1, dil=1, x=Ref(slab), ldx=LD, in_scale=Ref(sc1), in_shift=Ref(sh1), in_relu=1, in_mask=None, in_mask_ld=0, dz=Ref(y1), lddz=192, dw=Ref(dw1), ksplit=0)),
  'wgrad3x3': ('wgrad', dict(n_img=n, H=H, W=W, cin=192, cout=48, taps=9, dil=2, x=Ref(y1), ldx=192, in_scale=Ref(sc2), in_shift=Ref(sh2), in_relu=1, in_mask=None, in_mask_ld=0, dz=Ref(dz48), lddz=48, dw=Ref(dw2), ksplit=0)),
 }
@@ -51,5 +59,5 @@ for name, (kind, f) in cases.items():
     for _ in range(a.iters): be.call(kind, **f)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1)*1e3/a.iters
-    fl = 2.0*M*f['cout']*f['taps']*f['cin']
+    fl = 2.0*M*f['cout']*f['taps']*f['cin']*max(1, f.get('n_src', 0))
     print('%-14s %9.1f us  %7.1f TFLOP/s' % (name, us, fl/us/1e6), flush=True)
