@@ -12,6 +12,9 @@ typedef unsigned short u16;
 
 int dsaspp_set_error(const char* fmt, ...);
 
+// persistent grouped 1x1 data gradient (dgrad_group.hip): -1 = descriptor not of its form, 0 = launched
+int dsaspp_dgrad_group_launch(const dsaspp_conv_desc& d, hipStream_t s);
+
 #define DS_REQUIRE(cond, ...)                                  \
     do {                                                       \
         if (!(cond)) return dsaspp_set_error(__VA_ARGS__);     \
@@ -51,6 +54,21 @@ __device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
 __device__ __forceinline__ void store8f(float* p, const float (&f)[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+}
+
+// Sum over the 16 lanes of a DPP row (lanes 16k..16k+15); every lane of the row ends up with the total.
+// Four VALU adds with DPP operand swizzles (quad permutes, then the half-row and row mirrors) instead of
+// four LDS-pipe permutes.
+__device__ __forceinline__ float row16_sum(float v) {
+    int x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));   // row_half_mirror
+    x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
 }
 
 // Bijective XCD-aware block remap: blocks b and b+8 share an XCD (and its L2), so give each

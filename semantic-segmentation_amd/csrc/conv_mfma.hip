@@ -577,7 +577,15 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
                    "conv_fwd: null operand in an extra source");
         DS_REQUIRE((((uintptr_t)d.x1 | (uintptr_t)d.w1 | (uintptr_t)d.x2 | (uintptr_t)d.w2 | (uintptr_t)d.x3 | (uintptr_t)d.w3) & 15) == 0,
                    "conv_fwd: operands must be 16-byte aligned");
-        return launch_multi(d, s);
+        const int rc = dsaspp_dgrad_group_launch(d, s);
+        return rc >= 0 ? rc : launch_multi(d, s);
+    }
+    {   // experiment hook: DSASPP_DGRAD_GROUP=1 also routes single-source slab data gradients to the persistent kernel
+        static const int on = [] { const char* e = getenv("DSASPP_DGRAD_GROUP"); return e ? atoi(e) : 0; }();
+        if (on && d.g) {
+            const int rc = dsaspp_dgrad_group_launch(d, s);
+            if (rc >= 0) return rc;
+        }
     }
     const int co = d.cout;
     {   // experiment hook: DSASPP_CONV_TILE=<id> forces a tile for launches with cout > 64

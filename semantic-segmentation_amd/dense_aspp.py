@@ -138,7 +138,7 @@ class DenseASPP(nn.Module):
             if isinstance(m, nn.BatchNorm2d):
                 self.bn_modules[name] = m
         self.grad_slab_dtype = torch.float32     # torch.bfloat16 halves gradient-slab traffic (see Engine)
-        self.dgrad_group = 1                     # dense layers whose slab data gradients share one pass (1..4)
+        self.dgrad_group = 4                     # dense layers whose slab data gradients share one pass (1..4)
         self._flat = None
         self._gflat = None
         self._w16 = None

@@ -184,7 +184,7 @@ class Engine:
             self.tmp_b = zeros(big)          # fp32: input of the BatchNorm backward (see bn_bwd_apply)
             self.tmp_c = zeros(big, bf16)
             # bottleneck gradients of the layers whose slab data gradients are applied together
-            self.dgrad_group = max(1, min(4, int(getattr(model, 'dgrad_group', 1))))
+            self.dgrad_group = max(1, min(4, int(getattr(model, 'dgrad_group', 4))))
             self.dy1_bufs = [self.tmp_c] + [zeros(max(self.M1, self.M2) * cmax_mid, bf16) for _ in range(self.dgrad_group - 1)]
             self.coef = zeros(3 * max(sp.c_feat, cmax_mid, sp.c_stem))
             self.dw0pad = zeros(sp.c_stem * S.STEM_KPAD)

@@ -11,12 +11,14 @@ CLASSES = ['untimed',
            'conv_kernel<128,192,2,4>', 'conv_kernel<128,128,2,4>', 'conv_kernel<256,48,4,1>',
            'conv_kernel<128,64,2,2>', 'conv_kernel<128,32,4,1>',
            'wgrad_kernel<64,192,1,4>', 'wgrad_kernel<192,128,4,2>', 'wgrad_kernel<128,128,2,4>',
-           'upce_kernel<19>', 'wgrad_kernel<48,192,1,4>', 'wgrad_kernel<32,192,1,4>']
+           'upce_kernel<19>', 'wgrad_kernel<48,192,1,4>', 'wgrad_kernel<32,192,1,4>', 'dgrad_group_kernel']
 
 
 def kernel_class(kind, f):
     if kind == 'conv':
         co = f['cout']
+        if (f.get('n_src') or 0) > 1:
+            return 12
         if co <= 32:
             return 5
         if co <= 48:
@@ -45,7 +47,7 @@ def work(kind, f):
     """(flops, bytes) of one launch: algorithmic, i.e. what the operation needs, not what a kernel moves."""
     if kind in ('conv', 'wgrad'):
         M = f['n_img'] * f['H'] * f['W']
-        return 2.0 * M * f['cout'] * f['taps'] * f['cin'], 0.0
+        return 2.0 * M * f['cout'] * f['taps'] * f['cin'] * max(1, f.get('n_src') or 0), 0.0
     if kind == 'upce':
         m = f['n_img'] * f['h'] * f['w']
         # fp32 low-res logits read (n_class), int64 labels read, fp32 low-res gradient written
@@ -57,7 +59,7 @@ def role(kind, f):
     """Finer grouping used for reporting only: what the launch does in the network."""
     if kind == 'conv':
         if f.get('g') is not None:
-            return 'dgrad1x1->slab'
+            return 'dgrad1x1->slab x%d' % f['n_src'] if (f.get('n_src') or 0) > 1 else 'dgrad1x1->slab'
         if f.get('epi_relu'):
             return 'dgrad3x3' if f['taps'] == 9 else 'dgrad1x1'
         return 'fwd3x3' if f['taps'] == 9 else 'fwd1x1'
