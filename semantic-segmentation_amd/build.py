@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, 'csrc')
 ROOT = os.path.dirname(HERE)
 INCLUDE = os.path.join(ROOT, 'include')
 LIB = os.path.join(HERE, 'libdsaspp.so')
-SOURCES = ['conv_mfma.hip', 'dgrad_group.hip', 'wgrad_mfma.hip', 'elementwise.hip', 'loss.hip', 'optim.hip', 'program.hip']
+SOURCES = ['conv_mfma.hip', 'dgrad_group.hip', 'conv3x3_halo.hip', 'wgrad_mfma.hip', 'elementwise.hip', 'loss.hip', 'optim.hip', 'program.hip']
 
 
 def _hipcc():
@@ -20,7 +20,7 @@ def _hipcc():
 
 def build_library(force=False, verbose=False, extra_flags=()):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(INCLUDE, 'dsaspp.h')]
+    deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(INCLUDE, 'dsaspp.h'), os.path.abspath(__file__)]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
     objs = []

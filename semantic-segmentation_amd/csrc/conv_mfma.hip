@@ -587,6 +587,13 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
             if (rc >= 0) return rc;
         }
     }
+    if (d.taps == 9) {   // narrow-output 3x3 with a small dilation: halo-patch kernel (DSASPP_NO_HALO=1 disables it)
+        static const int off = [] { const char* e = getenv("DSASPP_NO_HALO"); return e ? atoi(e) : 0; }();
+        if (!off) {
+            const int rc = dsaspp_conv3x3_halo_launch(d, s);
+            if (rc >= 0) return rc;
+        }
+    }
     const int co = d.cout;
     {   // experiment hook: DSASPP_CONV_TILE=<id> forces a tile for launches with cout > 64
         static const int forced = [] { const char* e = getenv("DSASPP_CONV_TILE"); return e ? atoi(e) : 0; }();

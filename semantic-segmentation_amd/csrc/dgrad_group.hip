@@ -58,11 +58,16 @@ __device__ __forceinline__ Src get_src(const dsaspp_conv_desc& d, int s) {
 __device__ __forceinline__ void wait_vm(int younger_ops) {
     // wait until at most `younger_ops` vector-memory operations are outstanding (rounded down: safe)
     // (LDS operations of this wave are retired too, so that what it wrote is visible after the barrier)
-    if (younger_ops >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    if (younger_ops >= 24) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+    else if (younger_ops >= 20) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+    else if (younger_ops >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    else if (younger_ops >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else if (younger_ops >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     else if (younger_ops >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
+template <bool ACCG, bool GBF16>
 __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const dsaspp_conv_desc d, const int M, const int nP, const int nQ) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const dsaspp_conv_de
     const int frag_off0 = fr * 128 + ((fc ^ swz8(fr)) << 4);
     const int frag_off1 = fr * 128 + (((4 + fc) ^ swz8(fr)) << 4);
     const int rep = blockIdx.x % DS_R;
-    const bool acc_g = d.g_accumulate != 0;
+    constexpr bool acc_g = ACCG;
     float* stage = patch + wave * (16 * ROWF);
     const int er = lane >> 3, ec = lane & 7;
 
@@ -191,7 +196,35 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const dsaspp_conv_de
                 const bool ok = pok[j] && qok[i];
                 rfm[i][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(d.ref) + (ok ? p * d.ldref + q : 0));
             }
-        f32x4 tot[MQ][MP];
+        // old slab values of this tile, in the row layout of the final read-modify-write
+        constexpr int RPP = 8, NRP = 2;          // 8 lanes cover 32 channels of a pixel; 8 pixel rows per pass
+        const int q = q_base + wq * TQ + ec * 4;
+        float4 gold[MP][NRP];
+        bool okk[MP][NRP];
+#pragma unroll
+        for (int j = 0; j < MP; ++j)
+#pragma unroll
+            for (int rp = 0; rp < NRP; ++rp) {
+                const int64_t p = p_base + wp * TP + j * 16 + rp * RPP + er;
+                const bool ok = p < M && q < cout;
+                okk[j][rp] = ok;
+                if (acc_g) {
+                    const int64_t off = ok ? p * d.ldg + q : 0;
+                    if (GBF16) {
+                        const uint2 gb = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(d.g) + off);
+                        gold[j][rp] = make_float4(bf_lo(gb.x), bf_hi(gb.x), bf_lo(gb.y), bf_hi(gb.y));
+                    } else {
+                        gold[j][rp] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.g) + off);
+                    }
+                } else {
+                    gold[j][rp] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        // These loads (MQ*MP reference loads, MP*NRP slab loads) sit, in issue order, after the DMAs of the
+        // tile's first DEPTH steps: while one of those steps is awaited they may stay outstanding too.
+        const int n_ord = MQ * MP + (acc_g ? MP * NRP : 0);
+        const int g0 = g;
+        f32x4 tot[MQ][MP], xh[MQ][MP];
 #pragma unroll
         for (int i = 0; i < MQ; ++i)
 #pragma unroll
@@ -207,7 +240,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const dsaspp_conv_de
                 // stage g landed (this wave's DMAs), then everybody's; the barrier also says every wave
                 // is done reading stage g-1, whose ring slot the next DMA overwrites
                 const int younger = total_steps - 1 - g;
-                wait_vm(4 * (younger < DEPTH - 1 ? younger : DEPTH - 1));
+                wait_vm(4 * (younger < DEPTH - 1 ? younger : DEPTH - 1) + (g - g0 < DEPTH ? n_ord : 0));
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 issue();
@@ -230,6 +263,21 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const dsaspp_conv_de
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
                 }
             }
+            if (s == 0) {
+                // normalised reference activations, shared by every source's sums
+#pragma unroll
+                for (int i = 0; i < MQ; ++i) {
+                    const int cl = wq * TQ + i * 16 + fc * 4;
+                    const f32x4 mu4 = *reinterpret_cast<const f32x4*>(par + 8 * BQ + cl);
+                    const f32x4 rs4 = *reinterpret_cast<const f32x4*>(par + 9 * BQ + cl);
+#pragma unroll
+                    for (int j = 0; j < MP; ++j) {
+                        const uint2 rr = rfm[i][j];
+                        xh[i][j] = f32x4{(bf_lo(rr.x) - mu4[0]) * rs4[0], (bf_hi(rr.x) - mu4[1]) * rs4[1],
+                                         (bf_lo(rr.y) - mu4[2]) * rs4[2], (bf_hi(rr.y) - mu4[3]) * rs4[3]};
+                    }
+                }
+            }
             // ---- this source's product: ReLU mask, BatchNorm-backward sums, scaled add into the total
             const bool want_s = get_src(d, s).sa != nullptr;
 #pragma unroll
@@ -237,8 +285,6 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const dsaspp_conv_de
                 const int cl = wq * TQ + i * 16 + fc * 4;
                 const f32x4 sc4 = *reinterpret_cast<const f32x4*>(par + s * BQ + cl);
                 const f32x4 sh4 = *reinterpret_cast<const f32x4*>(par + (4 + s) * BQ + cl);
-                const f32x4 mu4 = *reinterpret_cast<const f32x4*>(par + 8 * BQ + cl);
-                const f32x4 rs4 = *reinterpret_cast<const f32x4*>(par + 9 * BQ + cl);
                 float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < MP; ++j) {
@@ -250,7 +296,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const dsaspp_conv_de
                         const float pre = fmaf(rf[e], sc4[e], sh4[e]);
                         const float v = (ok && pre > 0.f) ? acc[i][j][e] : 0.f;
                         s1[e] += v;
-                        s2[e] += v * ((rf[e] - mu4[e]) * rs4[e]);
+                        s2[e] = fmaf(v, xh[i][j][e], s2[e]);
                         tot[i][j][e] = fmaf(v, sc4[e], tot[i][j][e]);
                     }
                 }
@@ -289,29 +335,6 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const dsaspp_conv_de
         }
 
         // ---- slab read-modify-write through the wave-private patch, 16 pixels at a time
-        constexpr int RPP = 8, NRP = 2;          // 8 lanes cover 32 channels of a pixel; 8 pixel rows per pass
-        const int q = q_base + wq * TQ + ec * 4;
-        float4 gold[MP][NRP];
-        bool okk[MP][NRP];
-#pragma unroll
-        for (int j = 0; j < MP; ++j)
-#pragma unroll
-            for (int rp = 0; rp < NRP; ++rp) {
-                const int64_t p = p_base + wp * TP + j * 16 + rp * RPP + er;
-                const bool ok = p < M && q < cout;
-                okk[j][rp] = ok;
-                if (acc_g) {
-                    const int64_t off = ok ? p * d.ldg + q : 0;
-                    if (d.g_bf16) {
-                        const uint2 gb = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(d.g) + off);
-                        gold[j][rp] = make_float4(bf_lo(gb.x), bf_hi(gb.x), bf_lo(gb.y), bf_hi(gb.y));
-                    } else {
-                        gold[j][rp] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.g) + off);
-                    }
-                } else {
-                    gold[j][rp] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
 #pragma unroll
         for (int j = 0; j < MP; ++j) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -324,7 +347,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const dsaspp_conv_de
                 if (!okk[j][rp]) continue;
                 const int64_t p = p_base + wp * TP + j * 16 + rp * RPP + er;
                 const float4 t = make_float4(a4[0] + gold[j][rp].x, a4[1] + gold[j][rp].y, a4[2] + gold[j][rp].z, a4[3] + gold[j][rp].w);
-                if (d.g_bf16) {
+                if (GBF16) {
                     uint2 o;
                     o.x = pack_bf2(t.x, t.y);
                     o.y = pack_bf2(t.z, t.w);
@@ -354,14 +377,19 @@ int dsaspp_dgrad_group_launch(const dsaspp_conv_desc& d, hipStream_t s) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
             n_cu = 256;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_group_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_group_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_group_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_group_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     }
     int64_t tiles = (int64_t)nP * nQ;
     int grid = (int)((tiles + 7) / 8 * 8);
     const int cap = n_cu / 8 * 8;
     if (grid > cap) grid = cap;
     if (grid < 8) grid = 8;
-    hipLaunchKernelGGL(dgrad_group_kernel, dim3(grid), dim3(NT), LDS_BYTES, s, d, M, nP, nQ);
+    auto kern = d.g_accumulate ? (d.g_bf16 ? dgrad_group_kernel<true, true> : dgrad_group_kernel<true, false>)
+                               : (d.g_bf16 ? dgrad_group_kernel<false, true> : dgrad_group_kernel<false, false>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), LDS_BYTES, s, d, M, nP, nQ);
     DS_LAUNCH_CHECK("conv_fwd(grouped data gradient)");
     return 0;
 }

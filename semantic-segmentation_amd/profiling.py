@@ -11,7 +11,7 @@ CLASSES = ['untimed',
            'conv_kernel<128,192,2,4>', 'conv_kernel<128,128,2,4>', 'conv_kernel<256,48,4,1>',
            'conv_kernel<128,64,2,2>', 'conv_kernel<128,32,4,1>',
            'wgrad_kernel<64,192,1,4>', 'wgrad_kernel<192,128,4,2>', 'wgrad_kernel<128,128,2,4>',
-           'upce_kernel<19>', 'wgrad_kernel<48,192,1,4>', 'wgrad_kernel<32,192,1,4>', 'dgrad_group_kernel']
+           'upce_kernel<19>', 'wgrad_kernel<48,192,1,4>', 'wgrad_kernel<32,192,1,4>', 'dgrad_group_kernel', 'conv3x3_halo_kernel']
 
 
 def kernel_class(kind, f):
@@ -19,6 +19,10 @@ def kernel_class(kind, f):
         co = f['cout']
         if (f.get('n_src') or 0) > 1:
             return 12
+        if (f['taps'] == 9 and 1 <= f['dil'] <= 4 and co <= 64 and f['cin'] % 64 == 0 and f.get('g') is None
+                and not f.get('epi_relu') and f.get('s_acc') is None and not f.get('y_f32') and f.get('in_mask') is None
+                and f.get('bias') is None and f.get('out_mask') is None):
+            return 13
         if co <= 32:
             return 5
         if co <= 48:

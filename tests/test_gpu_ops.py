@@ -82,6 +82,9 @@ CONV_CASES = [
     dict(n=1, H=16, W=16, cin=128, cout=64, taps=9, dil=24),
     dict(n=1, H=8, W=8, cin=160, cout=16, taps=1, dil=1, scale=False, relu=False, stats=True),
     dict(n=3, H=8, W=16, cin=256, cout=40, taps=9, dil=1, stats=True),
+    dict(n=2, H=21, W=45, cin=128, cout=32, taps=9, dil=4, ldy=64, yoff=16, stats=True),
+    dict(n=1, H=19, W=70, cin=64, cout=64, taps=9, dil=3, scale=False, relu=False),
+    dict(n=2, H=16, W=64, cin=192, cout=48, taps=9, dil=1, scale=False, relu=True, stats=True),
 ]
 
 
