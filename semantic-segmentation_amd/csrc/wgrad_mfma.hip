@@ -8,7 +8,10 @@
 // the forward kernel -- and the fragments are fetched with the CDNA4 transposing LDS read
 // (ds_read_b64_tr_b16): each 16-lane group reads a 4-pixel x 16-channel block and every lane receives
 // the 4 pixels of its own channel.  One block owns a (BQ x BC) tile of one filter tap over a pixel
-// range; the partial sums of the pixel ranges are combined with fp32 atomics.
+// range; the partial sums of the pixel ranges are combined with fp32 atomics.  For the narrow 3x3
+// layers a block instead owns the three taps of one filter row (RT = 3): a K-step of 64 pixels lies
+// inside one image row, so the three horizontally shifted input windows are one staged tile of
+// 64 + 2*dilation pixels read at three row offsets, and the dz tile is shared as well.
 #include "common.h"
 
 namespace {
@@ -27,18 +30,21 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const int hal
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int BQ, int BC, int WQ, int WC, int PRO>
+constexpr int RT_MAXDIL = 8;   // largest dilation of the shared-row form (tile rows = BKP + 2*dilation)
+
+template <int BQ, int BC, int WQ, int WC, int PRO, int RT>
 __global__ __launch_bounds__(64 * WQ * WC, (WQ * WC == 8) ? 4 : 2) void wgrad_kernel(const dsaspp_wgrad_desc d, const int M,
                                                                                    const int nQ, const int nC,
                                                                                    const int chunk) {
     constexpr int NW = WQ * WC, NT = 64 * NW;
     constexpr int ZS = BQ + PADE, XS = BC + PADE;               // LDS row strides in elements
-    constexpr int Z_BYTES = BKP * ZS * 2, X_BYTES = BKP * XS * 2;
+    constexpr int XROWS = (RT == 3) ? BKP + 2 * RT_MAXDIL : BKP;   // staged input rows (upper bound)
+    constexpr int Z_BYTES = BKP * ZS * 2, X_BYTES = XROWS * XS * 2;
     constexpr int ZCH = BQ / 8, XCH = BC / 8;                   // 16-byte chunks per pixel row
     constexpr int ZLPR = (ZCH <= 4) ? 4 : (ZCH <= 8) ? 8 : (ZCH <= 16) ? 16 : 32;    // lanes per row (pow2 >= chunks)
     constexpr int XLPR = (XCH <= 4) ? 4 : (XCH <= 8) ? 8 : (XCH <= 16) ? 16 : 32;
     constexpr int ZRPP = NT / ZLPR, XRPP = NT / XLPR;           // rows per pass
-    constexpr int ZR = (BKP + ZRPP - 1) / ZRPP, XR = (BKP + XRPP - 1) / XRPP;
+    constexpr int ZR = (BKP + ZRPP - 1) / ZRPP, XR = (XROWS + XRPP - 1) / XRPP;
     constexpr int TQ = BQ / WQ, TC = BC / WC, MQ = TQ / 16, MC = TC / 16;
     static_assert(TQ % 16 == 0 && TC % 16 == 0, "wave tile");
 
@@ -52,8 +58,9 @@ __global__ __launch_bounds__(64 * WQ * WC, (WQ * WC == 8) ? 4 : 2) void wgrad_ke
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int ct = bid % nC; bid /= nC;
     const int qt = bid % nQ; bid /= nQ;
-    const int tap = bid % d.taps;
-    const int split = bid / d.taps;
+    const int ntapblk = d.taps / RT;
+    const int tap = (bid % ntapblk) * RT;      // first tap of this block
+    const int split = bid / ntapblk;
     const int q_base = qt * BQ, c_base = ct * BC;
     const int H = d.H, W = d.W, cin = d.cin, cout = d.cout;
     const int hw = H * W;
@@ -75,8 +82,9 @@ __global__ __launch_bounds__(64 * WQ * WC, (WQ * WC == 8) ? 4 : 2) void wgrad_ke
     if (d.taps == 9) {
         const int ty = tap / 3;
         dy = (ty - 1) * d.dil;
-        dx = (tap - ty * 3 - 1) * d.dil;
+        dx = (tap - ty * 3 - 1) * d.dil;      // RT == 3: -dil, the leftmost window; tile row r is pixel m0 + dx + r
     }
+    const int xrows = (RT == 3) ? BKP + 2 * d.dil : BKP;
 
     // ---- staging coordinates
     const int zc = tid % ZLPR, zr0 = tid / ZLPR;       // chunk column / first row of the dz tile
@@ -113,12 +121,14 @@ __global__ __launch_bounds__(64 * WQ * WC, (WQ * WC == 8) ? 4 : 2) void wgrad_ke
         for (int i = 0; i < XR; ++i) {
             const int row = xr0 + XRPP * i;
             const int m = m0 + row;
-            bool ok = xc_ok && row < BKP && m < m_end;
+            bool ok = xc_ok && row < xrows && (RT == 3 || m < m_end);
             int64_t pix = m;
             if (need_nhw) {
                 int n = n0, h = h0, w = w0 + row;
-                while (w >= W) { w -= W; ++h; }
-                while (h >= H) { h -= H; ++n; }
+                if (RT != 3) {            // RT == 3: the whole K-step lies in image row h0
+                    while (w >= W) { w -= W; ++h; }
+                    while (h >= H) { h -= H; ++n; }
+                }
                 const int hh = h + dy, ww = w + dx;
                 ok = ok && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
                 pix = ((int64_t)n * H + hh) * W + ww;
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(64 * WQ * WC, (WQ * WC == 8) ? 4 : 2) void wgrad_ke
             }
             const bool ok = xval[i];       // zero padding comes after the prologue
             v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-            if (xc < XCH && row < BKP) *reinterpret_cast<uint4*>(Xs + (row * XS + xc * 8) * 2) = v;
+            if (xc < XCH && row < xrows) *reinterpret_cast<uint4*>(Xs + (row * XS + xc * 8) * 2) = v;
         }
     };
 
@@ -173,11 +183,14 @@ __global__ __launch_bounds__(64 * WQ * WC, (WQ * WC == 8) ? 4 : 2) void wgrad_ke
     const int wq = wave % WQ, wc = wave / WQ;
     const int zfrag = ((g16 * 8 + (i16 >> 2)) * ZS + wq * TQ + (i16 & 3) * 4) * 2;
     const int xfrag = ((g16 * 8 + (i16 >> 2)) * XS + wc * TC + (i16 & 3) * 4) * 2;
-    f32x4 acc[MQ][MC];
+    f32x4 acc[RT][MQ][MC];
 #pragma unroll
-    for (int i = 0; i < MQ; ++i)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int j = 0; j < MC; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MQ; ++i)
+#pragma unroll
+            for (int j = 0; j < MC; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tstride = (RT == 3) ? d.dil * XS * 2 : 0;     // byte offset between the windows of neighbouring taps
 
     if (ksteps > 0) {
         gload(0);
@@ -188,16 +201,20 @@ __global__ __launch_bounds__(64 * WQ * WC, (WQ * WC == 8) ? 4 : 2) void wgrad_ke
             if (s + 1 < ksteps) gload(s + 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 zf[MQ], xf[MC];
+                bf16x8 zf[MQ];
 #pragma unroll
                 for (int i = 0; i < MQ; ++i) zf[i] = tr_frag(Zs + zfrag + (ks * 32 * ZS + i * 16) * 2, 4 * ZS * 2);
 #pragma unroll
-                for (int j = 0; j < MC; ++j) xf[j] = tr_frag(Xs + xfrag + (ks * 32 * XS + j * 16) * 2, 4 * XS * 2);
+                for (int t = 0; t < RT; ++t) {
+                    bf16x8 xf[MC];
 #pragma unroll
-                for (int i = 0; i < MQ; ++i)
+                    for (int j = 0; j < MC; ++j) xf[j] = tr_frag(Xs + xfrag + t * tstride + (ks * 32 * XS + j * 16) * 2, 4 * XS * 2);
 #pragma unroll
-                    for (int j = 0; j < MC; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[i], xf[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < MQ; ++i)
+#pragma unroll
+                        for (int j = 0; j < MC; ++j)
+                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[i], xf[j], acc[t][i][j], 0, 0, 0);
+                }
             }
             __syncthreads();
         }
@@ -207,35 +224,39 @@ __global__ __launch_bounds__(64 * WQ * WC, (WQ * WC == 8) ? 4 : 2) void wgrad_ke
     const int fr = lane & 15, fc = lane >> 4;
     const int Ktot = d.taps * cin;
 #pragma unroll
-    for (int i = 0; i < MQ; ++i) {
+    for (int t = 0; t < RT; ++t) {
 #pragma unroll
-        for (int j = 0; j < MC; ++j) {
-            const int c = c_base + wc * TC + j * 16 + fr;
-            if (c >= cin) continue;
+        for (int i = 0; i < MQ; ++i) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = q_base + wq * TQ + i * 16 + fc * 4 + r;
-                if (q < cout) atomicAdd(d.dw + (int64_t)q * Ktot + (int64_t)tap * cin + c, acc[i][j][r]);
+            for (int j = 0; j < MC; ++j) {
+                const int c = c_base + wc * TC + j * 16 + fr;
+                if (c >= cin) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = q_base + wq * TQ + i * 16 + fc * 4 + r;
+                    if (q < cout) atomicAdd(d.dw + (int64_t)q * Ktot + (int64_t)(tap + t) * cin + c, acc[t][i][j][r]);
+                }
             }
         }
     }
 }
 
-template <int BQ, int BC, int WQ, int WC, int PRO>
-int launch_pro(const dsaspp_wgrad_desc& d, hipStream_t s) {
+template <int BQ, int BC, int WQ, int WC, int PRO, int RT>
+int launch_rt(const dsaspp_wgrad_desc& d, hipStream_t s) {
     const int M = d.n_img * d.H * d.W;
     const int nQ = (d.cout + BQ - 1) / BQ, nC = (d.cin + BC - 1) / BC;
-    const int base_blocks = nQ * nC * d.taps;
+    const int base_blocks = nQ * nC * (d.taps / RT);
     int ksplit = d.ksplit;
     const int max_split = (M + 4 * BKP - 1) / (4 * BKP);   // at least 4 K-steps per block
-    if (ksplit <= 0) ksplit = 1024 / base_blocks;          // about two rounds of resident blocks
+    if (ksplit <= 0) ksplit = (RT == 3 ? 512 : 1024) / base_blocks;   // one (RT == 3) or two rounds of resident blocks
     if (ksplit > max_split) ksplit = max_split;
     if (ksplit < 1) ksplit = 1;
     int chunk = (M + ksplit - 1) / ksplit;
     chunk = (chunk + BKP - 1) / BKP * BKP;
     ksplit = (M + chunk - 1) / chunk;
-    const size_t lds = (size_t)BKP * (BQ + PADE + BC + PADE) * 2 + ((PRO != 0 && d.in_scale) ? (size_t)BC * 8 : 0);
-    auto kern = wgrad_kernel<BQ, BC, WQ, WC, PRO>;
+    const size_t lds = (size_t)BKP * (BQ + PADE) * 2 + (size_t)(RT == 3 ? BKP + 2 * RT_MAXDIL : BKP) * (BC + PADE) * 2 +
+                       ((PRO != 0 && d.in_scale) ? (size_t)BC * 8 : 0);
+    auto kern = wgrad_kernel<BQ, BC, WQ, WC, PRO, RT>;
     if (lds > 64 * 1024) {
         static thread_local bool done = false;
         if (!done) {
@@ -246,6 +267,13 @@ int launch_pro(const dsaspp_wgrad_desc& d, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(base_blocks * ksplit), dim3(64 * WQ * WC), lds, s, d, M, nQ, nC, chunk);
     DS_LAUNCH_CHECK("conv_wgrad");
     return 0;
+}
+
+template <int BQ, int BC, int WQ, int WC, int PRO>
+int launch_pro(const dsaspp_wgrad_desc& d, hipStream_t s) {
+    // shared-row form: narrow 3x3 layers whose 64-pixel K-steps never straddle an image row
+    if (BQ <= 64 && d.taps == 9 && d.W % BKP == 0 && d.dil <= RT_MAXDIL) return launch_rt<BQ, BC, WQ, WC, PRO, (BQ <= 64 ? 3 : 1)>(d, s);
+    return launch_rt<BQ, BC, WQ, WC, PRO, 1>(d, s);
 }
 
 template <int BQ, int BC, int WQ, int WC>

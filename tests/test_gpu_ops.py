@@ -159,6 +159,11 @@ WGRAD_CASES = [
     dict(n=2, H=12, W=12, cin=64, cout=128, taps=9, dil=3, lddz=136),
     dict(n=1, H=16, W=20, cin=160, cout=96, taps=1, dil=1, scale=False, relu=False),
     dict(n=2, H=10, W=10, cin=200, cout=336, taps=1, dil=1, ksplit=3),
+    # 64 | W: the three taps of a filter row share one staged input tile
+    dict(n=2, H=6, W=64, cin=192, cout=48, taps=9, dil=2),
+    dict(n=1, H=9, W=128, cin=136, cout=32, taps=9, dil=4, ldx=144, ksplit=3),
+    dict(n=2, H=5, W=64, cin=64, cout=64, taps=9, dil=1, scale=False, relu=True),
+    dict(n=1, H=12, W=64, cin=96, cout=40, taps=9, dil=8, scale=False, relu=False, in_mask=True),
 ]
 
 

@@ -50,8 +50,10 @@ cases = {
  'wgrad1x1': ('wgrad', dict(n_img=n, H=H, W=W, cin=CIN, cout=192, taps=1, dil=1, x=Ref(slab), ldx=LD, in_scale=Ref(sc1), in_shift=Ref(sh1), in_relu=1, in_mask=None, in_mask_ld=0, dz=Ref(y1), lddz=192, dw=Ref(dw1), ksplit=0)),
  'wgrad3x3': ('wgrad', dict(n_img=n, H=H, W=W, cin=192, cout=48, taps=9, dil=2, x=Ref(y1), ldx=192, in_scale=Ref(sc2), in_shift=Ref(sh2), in_relu=1, in_mask=None, in_mask_ld=0, dz=Ref(dz48), lddz=48, dw=Ref(dw2), ksplit=0)),
 }
+for ks in (140, 170, 200, 256):
+    kind, f = cases['wgrad3x3']; f = dict(f); f['ksplit'] = ks; cases['wgrad3x3_ks%d' % ks] = (kind, f)
 for name, (kind, f) in cases.items():
-    if a.only and name not in a.only.split(','): continue
+    if a.only and not any(name == o or (o.endswith('*') and name.startswith(o[:-1])) for o in a.only.split(',')): continue
     for _ in range(2): be.call(kind, **f)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
