@@ -157,8 +157,12 @@ def main():
                     gbs=(by * args.steps / (ms[t] * 1e-3) / 1e9) if by else None)
         mfma = {k: v for k, v in kernels.items() if v['tflops']}
         dom = max(mfma, key=lambda k: mfma[k]['ms_per_step'])
+        traffic = None                                  # HBM bytes per launch from the committed PMC passes, if any
+        tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+        if os.path.exists(tpath):
+            traffic = (json.load(open(tpath)).get(dom) or {}).get('hbm_bytes_per_launch')
         roofline = dict(bound='mfma', kernel=dom, achieved=round(mfma[dom]['tflops'], 2), peak=PEAK_BF16_TFLOPS,
-                        unit='TFLOP/s', frac=round(mfma[dom]['tflops'] / PEAK_BF16_TFLOPS, 4), traffic=None,
+                        unit='TFLOP/s', frac=round(mfma[dom]['tflops'] / PEAK_BF16_TFLOPS, 4), traffic=traffic,
                         avg_launch_us=round(mfma[dom]['avg_us'], 2), launches_per_step=mfma[dom]['launches_per_step'])
 
     if rank == 0:

@@ -137,7 +137,7 @@ class DenseASPP(nn.Module):
         for name, m in self.named_modules():
             if isinstance(m, nn.BatchNorm2d):
                 self.bn_modules[name] = m
-        self.grad_slab_dtype = torch.float32     # torch.bfloat16 halves gradient-slab traffic (see Engine)
+        self.grad_slab_dtype = torch.bfloat16    # dtype of the feature-slab gradient (torch.float32: exact accumulation, 2x traffic)
         self.dgrad_group = 4                     # dense layers whose slab data gradients share one pass (1..4)
         self._flat = None
         self._gflat = None
