@@ -4,22 +4,30 @@
 // ONCE per 64-channel chunk (BatchNorm scale/shift, ReLU and the zero padding applied on the way into
 // LDS), then runs all nine taps out of LDS by shifting the fragment base address.  LDS rows are one pixel
 // (64 channels = 128 B) padded to 160 B, which makes any 16 consecutive pixels conflict-free for
-// ds_read_b128 whatever the shift.  The few output channels make the filter small: its MFMA fragments are
-// read straight from global memory (L1/L2 resident), one tap ahead of use, and never touch LDS.
+// ds_read_b128 whatever the shift.  The chunk's filter slice (nine taps x few output channels) sits beside it
+// in XOR-swizzled 128-byte rows.  Patch and filter of the next chunk are loaded into registers while the nine
+// taps of the current one run.
 #include "common.h"
 
 namespace {
 
-constexpr int TH = 8, TW = 32, ROWB = 160, NT = 256;
+constexpr int TH = 8, TW = 32, ROWB = 160;
 
-template <int MQ>
+constexpr int NT = 512;
+
+template <int MQ, int DIL>
 __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const dsaspp_conv_desc d, const int tiles_x, const int tiles_y,
                                                             const int nblocks) {
-    constexpr int MP = 4;                               // per wave: 2 patch rows x 2 half rows of 16 pixels
+    constexpr int MP = 2;                               // per wave: one patch row = 2 half rows of 16 pixels
+    constexpr int HW2 = TW + 2 * DIL, HH2 = TH + 2 * DIL, NPIX = HW2 * HH2;
+    constexpr int NLD = (NPIX * 8 + NT - 1) / NT;       // staged 16-byte pieces of the patch per thread and chunk
+    constexpr int WROWS = 9 * MQ * 16;                  // filter rows [tap][channel] of one chunk, 128 B each
+    constexpr int NWL = (WROWS * 8 + NT - 1) / NT;
+    constexpr int XBYTES = NPIX * ROWB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wlds = smem + XBYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int H = d.H, W = d.W, cin = d.cin, cout = d.cout, dil = d.dil;
-    const int HW2 = TW + 2 * dil, HH2 = TH + 2 * dil, NPIX = HW2 * HH2;
+    const int H = d.H, W = d.W, cin = d.cin, cout = d.cout;
     const int bid = xcd_remap(blockIdx.x, nblocks);
     const int per_img = tiles_x * tiles_y;
     const int n = bid / per_img, rem = bid - n * per_img;
@@ -30,48 +38,50 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const dsaspp_conv_d
     const float relu_floor = d.in_relu ? 0.f : -3.0e38f;
     const bool has_scale = d.in_scale != nullptr;
 
-    // staging: item = tid + 256*it covers chunk column (tid & 7) of halo pixel item >> 3
+    // staging: piece u of this thread is chunk column (tid & 7) of halo pixel / filter row (tid >> 3) + 64 u
     const int ck = tid & 7;
-    const int nit = (NPIX * 8 + NT - 1) / NT;
+    int src_off[NLD], wsrc_off[NWL];
+    unsigned okmask = 0, wokmask = 0;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int pix = (tid >> 3) + u * (NT / 8);
+        const int hy = pix / HW2, hx = pix - hy * HW2;
+        const int iy = ty0 - DIL + hy, ix = tx0 - DIL + hx;
+        const bool ok = pix < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        okmask |= ok ? (1u << u) : 0u;
+        src_off[u] = ok ? ((n * H + iy) * W + ix) * d.ldx + ck * 8 : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < NWL; ++u) {
+        const int r = (tid >> 3) + u * (NT / 8);
+        const int tap = r / (MQ * 16), co = r - tap * (MQ * 16);
+        const bool ok = r < WROWS && co < cout;
+        wokmask |= ok ? (1u << u) : 0u;
+        wsrc_off[u] = ok ? (co * 9 + tap) * cin + ck * 8 : 0;
+    }
+    uint4 v[NLD], wv[NWL];
+    auto load_raw = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) v[u] = *reinterpret_cast<const uint4*>(xg + src_off[u] + c0);
+#pragma unroll
+        for (int u = 0; u < NWL; ++u) wv[u] = *reinterpret_cast<const uint4*>(wg + wsrc_off[u] + c0);
+    };
 
     // fragment coordinates
     const int fr = lane & 15, fc = lane >> 4;
     int rbase[MP];
 #pragma unroll
-    for (int j = 0; j < MP; ++j) {
-        const int ty = 2 * wave + (j >> 1), tx = (j & 1) * 16 + fr;
-        rbase[j] = ((ty + dil) * HW2 + tx + dil) * ROWB + fc * 16;
-    }
+    for (int j = 0; j < MP; ++j) rbase[j] = ((wave + DIL) * HW2 + j * 16 + fr + DIL) * ROWB + fc * 16;
+    const int woff0 = fr * 128 + ((fc ^ (fr & 7)) << 4), woff1 = fr * 128 + (((4 + fc) ^ (fr & 7)) << 4);
     f32x4 acc[MQ][MP];
 #pragma unroll
     for (int i = 0; i < MQ; ++i)
 #pragma unroll
         for (int j = 0; j < MP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int Ktot = 9 * cin;
-    const u16* wrow[MQ];
-    bool wok[MQ];
-#pragma unroll
-    for (int i = 0; i < MQ; ++i) {
-        const int co = i * 16 + fr;
-        wok[i] = co < cout;
-        wrow[i] = wg + (int64_t)(wok[i] ? co : 0) * Ktot + fc * 8;
-    }
 
-    constexpr int WD = (MQ == 2) ? 4 : (MQ == 3 ? 3 : 2);   // filter prefetch distance in taps
-    constexpr int SB = (MQ == 4) ? 8 : 16;              // staging loads in flight per thread
-    auto wload = [&](bf16x8 (&dst)[MQ][2], int tap, int c0) {
-#pragma unroll
-        for (int i = 0; i < MQ; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                uint4 t = *reinterpret_cast<const uint4*>(wrow[i] + tap * cin + c0 + ks * 32);
-                if (!wok[i]) t = make_uint4(0u, 0u, 0u, 0u);
-                dst[i][ks] = __builtin_bit_cast(bf16x8, t);
-            }
-    };
-
+    load_raw(0);
     for (int c0 = 0; c0 < cin; c0 += 64) {
-        // ---- stage the halo patch of channels [c0, c0+64)
+        // ---- BatchNorm + ReLU + zero padding on the way into LDS: channels [c0, c0+64) of the halo patch
         float sc[8], sh[8];
         if (has_scale) {
             load8f(d.in_scale + c0 + ck * 8, sc);
@@ -80,66 +90,63 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const dsaspp_conv_d
 #pragma unroll
             for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
         }
-        if (c0) __syncthreads();                        // every wave is done with the previous chunk's patch
-        int hx = tid >> 3, hy = 0;
-        while (hx >= HW2) { hx -= HW2; ++hy; }
-        // filter fragments of the chunk's first taps: in flight while the patch is staged
-        bf16x8 wb[WD + 1][MQ][2];
+        if (c0) __syncthreads();                        // every wave is done with the previous chunk
 #pragma unroll
-        for (int t = 0; t < WD; ++t) wload(wb[t], t, c0);
-        for (int it0 = 0; it0 < nit; it0 += SB) {
-            uint4 v[SB];
-            bool ok[SB];
-            int lds_off[SB];
+        for (int u = 0; u < NLD; ++u) {
+            float f[8];
+            unpack8(v[u], f);
 #pragma unroll
-            for (int u = 0; u < SB; ++u) {
-                const int pix = (tid >> 3) + (it0 + u) * (NT / 8);
-                const int iy = ty0 - dil + hy, ix = tx0 - dil + hx;
-                const bool inb = pix < NPIX;
-                ok[u] = inb && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                lds_off[u] = inb ? pix * ROWB + ck * 16 : -1;
-                const int64_t src = ok[u] ? (((int64_t)n * H + iy) * W + ix) * d.ldx + c0 + ck * 8 : 0;
-                v[u] = *reinterpret_cast<const uint4*>(xg + src);
-                hx += NT / 8;
-                if (hx >= HW2) { hx -= HW2; ++hy; }
-            }
+            for (int e = 0; e < 8; ++e) f[e] = fmaxf(fmaf(f[e], sc[e], sh[e]), relu_floor);
+            uint4 o = pack8(f);
+            const bool k = (okmask >> u) & 1u;          // zero padding comes after BatchNorm + ReLU
+            o.x = k ? o.x : 0u; o.y = k ? o.y : 0u; o.z = k ? o.z : 0u; o.w = k ? o.w : 0u;
+            const int pix = (tid >> 3) + u * (NT / 8);
+            if (pix < NPIX) *reinterpret_cast<uint4*>(smem + pix * ROWB + ck * 16) = o;
+        }
 #pragma unroll
-            for (int u = 0; u < SB; ++u) {
-                float f[8];
-                unpack8(v[u], f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = fmaxf(fmaf(f[e], sc[e], sh[e]), relu_floor);
-                uint4 o = pack8(f);
-                const bool k = ok[u];                   // zero padding comes after BatchNorm + ReLU
-                o.x = k ? o.x : 0u; o.y = k ? o.y : 0u; o.z = k ? o.z : 0u; o.w = k ? o.w : 0u;
-                if (lds_off[u] >= 0) *reinterpret_cast<uint4*>(smem + lds_off[u]) = o;
-            }
+        for (int u = 0; u < NWL; ++u) {
+            uint4 o = wv[u];
+            const bool k = (wokmask >> u) & 1u;
+            o.x = k ? o.x : 0u; o.y = k ? o.y : 0u; o.z = k ? o.z : 0u; o.w = k ? o.w : 0u;
+            const int r = (tid >> 3) + u * (NT / 8);
+            if (r < WROWS) *reinterpret_cast<uint4*>(wlds + r * 128 + ((ck ^ (r & 7)) << 4)) = o;
         }
         __syncthreads();
+        if (c0 + 64 < cin) load_raw(c0 + 64);           // next chunk: in flight during the nine taps
 
-        // ---- nine taps out of LDS; filter fragments WD taps ahead, straight from global memory
+        // ---- nine taps out of LDS
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap + WD < 9) wload(wb[(tap + WD) % (WD + 1)], tap + WD, c0);
             const int tyy = tap / 3, txx = tap - tyy * 3;
-            const int toff = ((tyy - 1) * dil * HW2 + (txx - 1) * dil) * ROWB;
+            const int toff = ((tyy - 1) * DIL * HW2 + (txx - 1) * DIL) * ROWB;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 af[MP];
+                bf16x8 af[MP], wf[MQ];
 #pragma unroll
                 for (int j = 0; j < MP; ++j) af[j] = *reinterpret_cast<const bf16x8*>(smem + rbase[j] + toff + ks * 64);
 #pragma unroll
                 for (int i = 0; i < MQ; ++i)
+                    wf[i] = *reinterpret_cast<const bf16x8*>(wlds + (tap * MQ + i) * 2048 + (ks ? woff1 : woff0));
+#pragma unroll
+                for (int i = 0; i < MQ; ++i)
 #pragma unroll
                     for (int j = 0; j < MP; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[tap % (WD + 1)][i][ks], af[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
             }
         }
     }
 
     // ---- epilogue: bf16 NHWC store into the slab slice, statistics of the stored values
+    // Statistics go through one LDS reduction per block and leave as a few full-width atomic instructions:
+    // float atomics execute at the memory side, an instruction with 4 active lanes costs what a full one does.
     const bool want_stats = d.stat_acc != nullptr;
     const int rep = blockIdx.x % DS_R;
+    float* red = reinterpret_cast<float*>(smem);        // [2][MQ*16]
+    if (want_stats) {
+        __syncthreads();                                // the patch is dead
+        if (tid < 2 * MQ * 16) red[tid] = 0.f;
+        __syncthreads();
+    }
     u16* yg = reinterpret_cast<u16*>(d.y);
 #pragma unroll
     for (int i = 0; i < MQ; ++i) {
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const dsaspp_conv_d
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < MP; ++j) {
-            const int oy = ty0 + 2 * wave + (j >> 1), ox = tx0 + (j & 1) * 16 + fr;
+            const int oy = ty0 + wave, ox = tx0 + j * 16 + fr;
             if (oy < H && ox < W && co < cout) {
                 uint2 o;
                 o.x = pack_bf2(acc[i][j][0], acc[i][j][1]);
@@ -164,24 +171,31 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const dsaspp_conv_d
                 s1[e] = row16_sum(s1[e]);
                 s2[e] = row16_sum(s2[e]);
             }
-            if (fr == 0 && co < cout) {
-                float* base = d.stat_acc + (size_t)rep * 2 * cout;
+            if (fr == 0) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    atomicAdd(base + co + e, s1[e]);
-                    atomicAdd(base + cout + co + e, s2[e]);
+                    atomicAdd(red + co + e, s1[e]);
+                    atomicAdd(red + MQ * 16 + co + e, s2[e]);
                 }
             }
         }
     }
+    if (want_stats) {
+        __syncthreads();
+        if (tid < 2 * MQ * 16) {
+            const int half = tid / (MQ * 16), c = tid - half * (MQ * 16);
+            if (c < cout) atomicAdd(d.stat_acc + (size_t)rep * 2 * cout + half * cout + c, red[tid]);
+        }
+    }
 }
 
-template <int MQ>
+template <int MQ, int DIL>
 int launch_halo(const dsaspp_conv_desc& d, hipStream_t s) {
     const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
     const int nblocks = d.n_img * tiles_x * tiles_y;
-    const size_t lds = (size_t)(TW + 2 * d.dil) * (TH + 2 * d.dil) * ROWB;
-    auto kern = conv3x3_halo_kernel<MQ>;
+    const size_t lds = (size_t)(TW + 2 * DIL) * (TH + 2 * DIL) * ROWB + (size_t)9 * MQ * 16 * 128;
+    if (lds > 160 * 1024) return -1;                    // patch + filter slice do not fit: generic kernel
+    auto kern = conv3x3_halo_kernel<MQ, DIL>;
     static thread_local bool done = false;
     if (!done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -192,6 +206,16 @@ int launch_halo(const dsaspp_conv_desc& d, hipStream_t s) {
     return 0;
 }
 
+template <int MQ>
+int launch_dil(const dsaspp_conv_desc& d, hipStream_t s) {
+    switch (d.dil) {
+        case 1: return launch_halo<MQ, 1>(d, s);
+        case 2: return launch_halo<MQ, 2>(d, s);
+        case 3: return launch_halo<MQ, 3>(d, s);
+        default: return launch_halo<MQ, 4>(d, s);
+    }
+}
+
 }  // namespace
 
 // -1: not of this kernel's form (the caller falls back to the generic kernel); 0: launched.
@@ -199,7 +223,8 @@ int dsaspp_conv3x3_halo_launch(const dsaspp_conv_desc& d, hipStream_t s) {
     const bool form = d.taps == 9 && d.dil >= 1 && d.dil <= 4 && d.cout <= 64 && d.cin % 64 == 0 && !d.in_mask && !d.bias && !d.out_mask &&
                       !d.y_f32 && !d.epi_relu && !d.s_acc && !d.g && d.y;
     if (!form) return -1;
-    if (d.cout <= 32) return launch_halo<2>(d, s);
-    if (d.cout <= 48) return launch_halo<3>(d, s);
-    return launch_halo<4>(d, s);
+    if ((int64_t)d.n_img * d.H * d.W * d.ldx >= (1ll << 31)) return -1;      // 32-bit element offsets inside
+    if (d.cout <= 32) return launch_dil<2>(d, s);
+    if (d.cout <= 48) return launch_dil<3>(d, s);
+    return launch_dil<4>(d, s);
 }

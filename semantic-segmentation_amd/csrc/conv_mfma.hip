@@ -340,9 +340,10 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
     constexpr int NCB = TQ / CBW;
     constexpr int NRP = 16 / RPP;
     constexpr int ROWF = TQ + 4;                    // padded row stride in floats (bank spread)
-    static_assert(NW * 16 * ROWF * 4 + 5 * BQ * 4 <= A_BYTES + W_BYTES, "epilogue LDS fits in the staging buffers");
+    static_assert(NW * 16 * ROWF * 4 + 7 * BQ * 4 <= A_BYTES + W_BYTES, "epilogue LDS fits in the staging buffers");
     float* stage = reinterpret_cast<float*>(smem) + wave * (16 * ROWF);
     float* epar = reinterpret_cast<float*>(smem) + NW * 16 * ROWF;     // [5][BQ]: bias, scale, shift, mean, rstd
+    float* red = epar + 5 * BQ;                                        // [2][BQ]: block-level sums
     const bool want_stats = (EPI < 2) && (d.stat_acc != nullptr);
     const bool want_s = (EPI == 1 || EPI == 2) && d.s_acc != nullptr;
     const bool need_ref = (EPI == 1 || EPI == 2) && (d.epi_relu || want_s);
@@ -355,6 +356,8 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
         epar[2 * BQ + c] = (ok && d.e_scale) ? d.e_shift[q] : 0.f;
         epar[3 * BQ + c] = (ok && want_s) ? d.e_mean[q] : 0.f;
         epar[4 * BQ + c] = (ok && want_s) ? d.e_rstd[q] : 1.f;
+        red[c] = 0.f;
+        red[BQ + c] = 0.f;
     }
     const int er = lane / LPR, ec = lane % LPR;
     float st_a[NCB][4], st_b[NCB][4];
@@ -479,8 +482,8 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
         }
     }
     if (want_stats || want_s) {
-        const int sld = (want_s && d.s_ld > 0) ? d.s_ld : cout;
-        float* base = (want_s ? d.s_acc : d.stat_acc) + (size_t)rep * 2 * sld;
+        // Block-level reduction in LDS, then one full-width atomic instruction per 64 channels: float atomics
+        // execute at the memory side and an instruction with a few active lanes costs what a full one does.
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
@@ -492,14 +495,21 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
                     st_b[cb][e] += __shfl_xor(st_b[cb][e], o, 64);
                 }
             }
-            const int q = q_base + wq * TQ + cb * CBW + ec * 4;
-            if (er == 0 && q < cout) {
+            const int cl = wq * TQ + cb * CBW + ec * 4;
+            if (er == 0) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    atomicAdd(base + q + e, st_a[cb][e]);
-                    atomicAdd(base + sld + q + e, st_b[cb][e]);
+                    atomicAdd(red + cl + e, st_a[cb][e]);
+                    atomicAdd(red + BQ + cl + e, st_b[cb][e]);
                 }
             }
+        }
+        __syncthreads();
+        const int sld = (want_s && d.s_ld > 0) ? d.s_ld : cout;
+        float* base = (want_s ? d.s_acc : d.stat_acc) + (size_t)rep * 2 * sld;
+        for (int c = tid; c < 2 * BQ; c += NT) {
+            const int half = c / BQ, cc = c - half * BQ;
+            if (q_base + cc < cout) atomicAdd(base + half * sld + q_base + cc, red[c]);
         }
     }
 }

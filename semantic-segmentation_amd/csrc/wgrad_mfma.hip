@@ -248,7 +248,7 @@ int launch_rt(const dsaspp_wgrad_desc& d, hipStream_t s) {
     const int base_blocks = nQ * nC * (d.taps / RT);
     int ksplit = d.ksplit;
     const int max_split = (M + 4 * BKP - 1) / (4 * BKP);   // at least 4 K-steps per block
-    if (ksplit <= 0) ksplit = (RT == 3 ? 512 : 1024) / base_blocks;   // one (RT == 3) or two rounds of resident blocks
+    if (ksplit <= 0) ksplit = 512 / base_blocks;           // one round of resident blocks: the fewest atomic epilogues
     if (ksplit > max_split) ksplit = max_split;
     if (ksplit < 1) ksplit = 1;
     int chunk = (M + ksplit - 1) / ksplit;

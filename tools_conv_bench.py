@@ -35,6 +35,7 @@ def conv(**kw):
 cases = {
  'fwd1x1': conv(n_img=n, H=H, W=W, cin=CIN, cout=192, taps=1, dil=1, x=Ref(slab), ldx=LD, w=Ref(w1), in_scale=Ref(sc1), in_shift=Ref(sh1), in_relu=1, y=Ref(y1), ldy=192, stat_acc=Ref(acc)),
  'fwd3x3': conv(n_img=n, H=H, W=W, cin=192, cout=48, taps=9, dil=2, x=Ref(y1), ldx=192, w=Ref(w2), in_scale=Ref(sc2), in_shift=Ref(sh2), in_relu=1, y=Ref(slab, CIN), ldy=LD, stat_acc=Ref(acc)),
+ 'fwd3x3_d4': conv(n_img=n, H=H, W=W, cin=192, cout=48, taps=9, dil=4, x=Ref(y1), ldx=192, w=Ref(w2), in_scale=Ref(sc2), in_shift=Ref(sh2), in_relu=1, y=Ref(slab, CIN), ldy=LD, stat_acc=Ref(acc)),
  'dgrad3x3': conv(n_img=n, H=H, W=W, cin=48, cout=192, taps=9, dil=2, x=Ref(dz48), ldx=48, w=Ref(w2t), y=Ref(dr), ldy=192, y_f32=1, epi_relu=1, ref=Ref(y1), ldref=192, e_scale=Ref(sc2), e_shift=Ref(sh2), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc)),
  'dgrad1x1_slab': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc), g=Ref(g), ldg=LD, g_accumulate=1),
  'dgrad1x1_slab16': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc), g=Ref(g16), ldg=LD, g_accumulate=1, g_bf16=1),
@@ -50,16 +51,21 @@ cases = {
  'wgrad1x1': ('wgrad', dict(n_img=n, H=H, W=W, cin=CIN, cout=192, taps=1, dil=1, x=Ref(slab), ldx=LD, in_scale=Ref(sc1), in_shift=Ref(sh1), in_relu=1, in_mask=None, in_mask_ld=0, dz=Ref(y1), lddz=192, dw=Ref(dw1), ksplit=0)),
  'wgrad3x3': ('wgrad', dict(n_img=n, H=H, W=W, cin=192, cout=48, taps=9, dil=2, x=Ref(y1), ldx=192, in_scale=Ref(sc2), in_shift=Ref(sh2), in_relu=1, in_mask=None, in_mask_ld=0, dz=Ref(dz48), lddz=48, dw=Ref(dw2), ksplit=0)),
 }
-for ks in (140, 170, 200, 256):
+for dbg in (2, 4, 8, 6):
+    kind, f = cases['fwd3x3']; f = dict(f); f['in_mask_ld'] = dbg; cases['fwd3x3_dbg%d' % dbg] = (kind, f)
+for ks in (25, 38, 51, 76):
+    kind, f = cases['wgrad1x1']; f = dict(f); f['ksplit'] = ks; cases['wgrad1x1_ks%d' % ks] = (kind, f)
+for ks in ():
     kind, f = cases['wgrad3x3']; f = dict(f); f['ksplit'] = ks; cases['wgrad3x3_ks%d' % ks] = (kind, f)
 for name, (kind, f) in cases.items():
     if a.only and not any(name == o or (o.endswith('*') and name.startswith(o[:-1])) for o in a.only.split(',')): continue
-    for _ in range(2): be.call(kind, **f)
-    torch.cuda.synchronize()
+    from semantic_segmentation_amd.engine import OpList
+    ops = OpList()
+    for _ in range(a.iters): ops.op(kind, **f)
+    prog = be.compile(ops)            # replayed by the C++ runner: no per-launch Python time in the measurement
+    prog.run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(a.iters): be.call(kind, **f)
-    e1.record(); torch.cuda.synchronize()
+    e0.record(); prog.run(); e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1)*1e3/a.iters
     fl = 2.0*M*f['cout']*f['taps']*f['cin']*max(1, f.get('n_src', 0))
     print('%-14s %9.1f us  %7.1f TFLOP/s' % (name, us, fl/us/1e6), flush=True)
