@@ -590,12 +590,9 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
         const int rc = dsaspp_dgrad_group_launch(d, s);
         return rc >= 0 ? rc : launch_multi(d, s);
     }
-    {   // experiment hook: DSASPP_DGRAD_GROUP=1 also routes single-source slab data gradients to the persistent kernel
-        static const int on = [] { const char* e = getenv("DSASPP_DGRAD_GROUP"); return e ? atoi(e) : 0; }();
-        if (on && d.g) {
-            const int rc = dsaspp_dgrad_group_launch(d, s);
-            if (rc >= 0) return rc;
-        }
+    if (d.g && d.cout >= 192) {   // wide slab data gradients of the masked form: persistent DMA-fed kernel
+        const int rc = dsaspp_dgrad_group_launch(d, s);
+        if (rc >= 0) return rc;
     }
     if (d.taps == 9) {   // narrow-output 3x3 with a small dilation: halo-patch kernel (DSASPP_NO_HALO=1 disables it)
         static const int off = [] { const char* e = getenv("DSASPP_NO_HALO"); return e ? atoi(e) : 0; }();

@@ -138,6 +138,7 @@ class DenseASPP(nn.Module):
             if isinstance(m, nn.BatchNorm2d):
                 self.bn_modules[name] = m
         self.grad_slab_dtype = torch.bfloat16    # dtype of the feature-slab gradient (torch.float32: exact accumulation, 2x traffic)
+        self.bn_grad_dtype = torch.bfloat16      # dtype of the BatchNorm-backward inputs (torch.float32: unrounded)
         self.dgrad_group = 4                     # dense layers whose slab data gradients share one pass (1..4)
         self._flat = None
         self._gflat = None

@@ -181,7 +181,9 @@ class Engine:
             big = max(self.M0 * sp.c_stem, self.M2 * sp.c_feat, self.M1 * sp.blocks[0].cout,
                       self.M1 * cmax_mid, self.M2 * cmax_mid)
             self.tmp_a = zeros(big, bf16)
-            self.tmp_b = zeros(big)          # fp32: input of the BatchNorm backward (see bn_bwd_apply)
+            # input of the BatchNorm backward (see bn_bwd_apply): bf16 like every other activation gradient, or fp32
+            self.dr_f32 = int(getattr(model, 'bn_grad_dtype', torch.bfloat16) == torch.float32 or bf16 != torch.bfloat16)
+            self.tmp_b = zeros(big) if self.dr_f32 else zeros(big, bf16)
             self.tmp_c = zeros(big, bf16)
             # bottleneck gradients of the layers whose slab data gradients are applied together
             self.dgrad_group = max(1, min(4, int(getattr(model, 'dgrad_group', 4))))
@@ -438,7 +440,7 @@ class Engine:
                    corr1=_r(slab.corr, c0), corr2=_r(slab.corr, slab.C + c0), mean=None, rstd=None)
 
         def bn_apply(C_, M_, dr, y, dy, colsum=None):
-            ops.op('bn_bwd_apply', M=M_, C=C_, dr=_r(dr), lddr=C_, dr_f32=1, y=_r(y), ldy=C_, coefA=_r(self.coef, 0),
+            ops.op('bn_bwd_apply', M=M_, C=C_, dr=_r(dr), lddr=C_, dr_f32=self.dr_f32, y=_r(y), ldy=C_, coefA=_r(self.coef, 0),
                    coefB=_r(self.coef, C_), coefC=_r(self.coef, 2 * C_), dy=_r(dy), lddy=C_, colsum=colsum)
 
         dz, dr, dy1 = self.tmp_a, self.tmp_b, self.tmp_c
@@ -463,7 +465,7 @@ class Engine:
                in_scale=self.bnt(n2, 'scale', a.d0), in_shift=self.bnt(n2, 'shift', a.d0), in_relu=1, dz=_r(dz),
                lddz=a.d1, dw=self.PG(a.prefix + '.conv2.weight'))
             C(n_img=B, H=H, W=W, cin=a.d1, cout=a.d0, taps=9, dil=a.rate, x=_r(dz), ldx=a.d1,
-              w=self.WT16(a.prefix + '.conv2.weight'), y=_r(dr), ldy=a.d0, y_f32=1, epi_relu=1, ref=_r(y1), ldref=a.d0,
+              w=self.WT16(a.prefix + '.conv2.weight'), y=_r(dr), ldy=a.d0, y_f32=self.dr_f32, epi_relu=1, ref=_r(y1), ldref=a.d0,
               e_scale=self.bnt(n2, 'scale', a.d0), e_shift=self.bnt(n2, 'shift', a.d0),
               e_mean=self.bnt(n2, 'mean', a.d0), e_rstd=self.bnt(n2, 'rstd', a.d0), s_acc=_r(self.acc[a.prefix + '.s2']))
             bn_bwd(n2, a.d0, a.prefix + '.s2', M, 0)
@@ -491,7 +493,7 @@ class Engine:
         n5 = 'features.norm5'
         slab_extract(A, sp.off_feat, cf, dr, relu=1, yref=_r(self.t4out), ldyref=cf, r_scale=self.bnt(n5, 'scale', cf),
                      r_shift=self.bnt(n5, 'shift', cf), r_mean=self.bnt(n5, 'mean', cf), r_rstd=self.bnt(n5, 'rstd', cf),
-                     s_acc=_r(self.acc['features.norm5.s']), dz_f32=1)
+                     s_acc=_r(self.acc['features.norm5.s']), dz_f32=self.dr_f32)
         bn_bwd(n5, cf, 'features.norm5.s', M, 0)
         bn_apply(cf, M, dr, self.t4out, dz)
         dz_cur = dz            # gradient w.r.t. the output of the last transition conv, [M2][cout]
@@ -542,7 +544,7 @@ class Engine:
                        in_scale=self.bnt(n2, 'scale', l.mid), in_shift=self.bnt(n2, 'shift', l.mid), in_relu=1, dz=_r(dz),
                        lddz=l.growth, dw=self.PG(l.prefix + '.conv2.weight'))
                     C(n_img=B, H=H, W=W, cin=l.growth, cout=l.mid, taps=9, dil=l.dil, x=_r(dz), ldx=l.growth,
-                      w=self.WT16(l.prefix + '.conv2.weight'), y=_r(dr), ldy=l.mid, y_f32=1, epi_relu=1, ref=_r(y1), ldref=l.mid,
+                      w=self.WT16(l.prefix + '.conv2.weight'), y=_r(dr), ldy=l.mid, y_f32=self.dr_f32, epi_relu=1, ref=_r(y1), ldref=l.mid,
                       e_scale=self.bnt(n2, 'scale', l.mid), e_shift=self.bnt(n2, 'shift', l.mid),
                       e_mean=self.bnt(n2, 'mean', l.mid), e_rstd=self.bnt(n2, 'rstd', l.mid),
                       s_acc=_r(self.acc[l.prefix + '.s2']))
@@ -579,7 +581,7 @@ class Engine:
         slab_extract(s1, 0, cs, dz)
         ops.op('maxpool_bwd', n_img=B, H=self.H0, W=self.W0, C=cs, x=_r(self.c0out), ldx=cs,
                scale=self.bnt(n0, 'scale', cs), shift=self.bnt(n0, 'shift', cs), y=None, ldy=0, argmax=_r(self.argmax0),
-               stat_acc=None, dy=_r(dz), lddy=cs, dr=_r(dr), lddr=cs, dr_f32=1, mean=self.bnt(n0, 'mean', cs),
+               stat_acc=None, dy=_r(dz), lddy=cs, dr=_r(dr), lddr=cs, dr_f32=self.dr_f32, mean=self.bnt(n0, 'mean', cs),
                rstd=self.bnt(n0, 'rstd', cs), s_acc=_r(self.acc['features.norm0']))
         bn_bwd(n0, cs, 'features.norm0', self.M0, 0)
         bn_apply(cs, self.M0, dr, self.c0out, dy1)

@@ -17,7 +17,11 @@ CLASSES = ['untimed',
 def kernel_class(kind, f):
     if kind == 'conv':
         co = f['cout']
-        if (f.get('n_src') or 0) > 1:
+        if (f.get('n_src') or 0) > 1 or (
+                f.get('g') is not None and co >= 192 and f['taps'] == 1 and f.get('epi_relu') and f.get('ref') is not None
+                and f.get('e_scale') is not None and f.get('e_mean') is not None and f.get('in_scale') is None
+                and f.get('in_mask') is None and not f.get('in_relu') and f.get('bias') is None and f.get('out_mask') is None
+                and f['cin'] % 64 == 0 and f['cin'] <= 1024):
             return 12
         if (f['taps'] == 9 and 1 <= f['dil'] <= 4 and co <= 64 and f['cin'] % 64 == 0 and f.get('g') is None
                 and not f.get('epi_relu') and f.get('s_acc') is None and not f.get('y_f32') and f.get('in_mask') is None
