@@ -4,8 +4,8 @@
 // a lane owns one full-resolution column of one "cell" -- the 8x8 block of output pixels that
 // interpolates between the same four low-resolution corners -- walks its 8 rows, and keeps
 // the x-interpolated corner rows and the per-corner-row gradient sums in registers.  The 8
-// lanes of a cell are combined with shuffles; one lane group per cell then adds the 4 x n_class
-// corner gradients to the low-resolution gradient with fp32 atomics.  HBM traffic is the
+// lanes of a cell are combined with DPP adds; the cells of a block meet in an LDS tile of the
+// low-resolution gradient, which leaves as contiguous fp32 atomics.  HBM traffic is the
 // low-resolution logits, the int64 labels and the low-resolution gradient.
 #include "common.h"
 
@@ -24,32 +24,46 @@ __device__ __forceinline__ void src_index(int o, int n, int& i0, int& i1, float&
 }
 
 // Cells: cell row j in [0, h] covers output rows [8j-4, 8j+4) ; same for columns.  All rows of
-// a cell share (i0, i1).
-template <int NC>
-__global__ __launch_bounds__(256) void upce_kernel(const dsaspp_ce_desc d) {
+// a cell share (i0, i1).  A block owns a tile of UP_TCX x UP_TCY cells; the corner gradients of its
+// cells are summed in an LDS copy of the (UP_TCX+1) x (UP_TCY+1) low-resolution pixels the tile
+// touches and leave as one pass of contiguous fp32 atomics (pixels on the tile border are shared
+// with the neighbouring blocks).
+constexpr int UP_TCX = 8, UP_TCY = 4;
+
+__device__ __forceinline__ float row8_sum(float v) {
+    // sum over the 8 lanes of a cell (aligned 8-lane groups inside a DPP row), result in every lane
+    int x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));   // row_half_mirror
+    return v;
+}
+
+// EXACT: n_class == NC, no per-class range checks (they are scalar conditions: the compiler turns each into a
+// branch and the unrolled class loops into thousands of lines of duplicated code)
+template <int NC, bool EXACT>
+__global__ __launch_bounds__(256) void upce_kernel(const dsaspp_ce_desc d, const int tiles_x, const int tiles_y) {
+    constexpr int PX = UP_TCX + 1, PY = UP_TCY + 1, CS = NC + 1;     // LDS tile [PY][PX][CS]
+    __shared__ float gt[PY * PX * CS];
     const int h = d.h, w = d.w, H = 8 * h, W = 8 * w;
     const int cells_x = w + 1, cells_y = h + 1;
-    const int lane8 = threadIdx.x & 7;
-    const int64_t cell = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
-    const int64_t ncell = (int64_t)d.n_img * cells_y * cells_x;
-    const bool cell_ok = cell < ncell;
-    int n = 0, cj = 0, ci = 0;
-    if (cell_ok) {
-        n = (int)(cell / (cells_y * cells_x));
-        const int rem = (int)(cell - (int64_t)n * cells_y * cells_x);
-        cj = rem / cells_x;
-        ci = rem - cj * cells_x;
-    }
+    const int tid = threadIdx.x, lane8 = tid & 7;
+    int b = blockIdx.x;
+    const int bx = b % tiles_x; b /= tiles_x;
+    const int by = b % tiles_y;
+    const int n = b / tiles_y;
+    const int ci = bx * UP_TCX + ((tid >> 3) & (UP_TCX - 1)), cj = by * UP_TCY + (tid >> 6);
+    const bool cell_ok = ci < cells_x && cj < cells_y;
+    for (int i = tid; i < PY * PX * CS; i += 256) gt[i] = 0.f;
     const int X = 8 * ci - 4 + lane8;
     const bool col_ok = cell_ok && X >= 0 && X < W;
     int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
     float lx = 0.f, ly_dummy = 0.f;
     src_index(max(X, 0), w, x0, x1, lx);
     // corner rows of this cell (identical for all its rows)
-    {
-        const int Yfirst = max(8 * cj - 4, 0);
-        src_index(Yfirst, h, y0, y1, ly_dummy);
-    }
+    src_index(max(8 * cj - 4, 0), h, y0, y1, ly_dummy);
     const float hx = 1.f - lx;
     const float* L = d.logits + (int64_t)n * h * w * d.ldl;
     float r0[NC], r1[NC], g0[NC], g1[NC];
@@ -63,13 +77,20 @@ __global__ __launch_bounds__(256) void upce_kernel(const dsaspp_ce_desc d) {
         const float* p11 = L + ((int64_t)y1 * w + x1) * d.ldl;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            if (c < d.n_class) {
-                r0[c] = hx * p00[c] + lx * p01[c];
-                r1[c] = hx * p10[c] + lx * p11[c];
-            }
+            // classes past n_class sit at -1e30: they never win the max and their exp() is exactly 0, so the row
+            // loop needs no per-class range checks
+            const bool cv = EXACT || c < d.n_class;
+            r0[c] = cv ? hx * p00[cv ? c : 0] + lx * p01[cv ? c : 0] : -1.0e30f;
+            r1[c] = cv ? hx * p10[cv ? c : 0] + lx * p11[cv ? c : 0] : -1.0e30f;
         }
         const int64_t* lab = d.labels + (int64_t)n * H * W;
-#pragma unroll 1
+        int tl[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {              // the 8 labels of this lane's column: loads in flight together
+            const int Y = 8 * cj - 4 + r;
+            tl[r] = (Y >= 0 && Y < H) ? (int)lab[(int64_t)Y * W + X] : d.ignore_index;
+        }
+#pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int Y = 8 * cj - 4 + r;
             const bool row_ok = Y >= 0 && Y < H;
@@ -77,20 +98,23 @@ __global__ __launch_bounds__(256) void upce_kernel(const dsaspp_ce_desc d) {
             float ly;
             src_index(row_ok ? Y : 0, h, yy0, yy1, ly);
             const float hy = 1.f - ly;
-            const int t = row_ok ? (int)lab[(int64_t)Y * W + X] : d.ignore_index;
+            const int t = tl[r];
             const float live = (t != d.ignore_index) ? 1.f : 0.f;
+            // one-hot of the target as a bit mask: keeps the per-class selects plain arithmetic (a chain of
+            // (c == t) selects gets lowered to a jump table over t with one copy of the row body per class)
+            const unsigned tm = ((unsigned)t < 32u) ? (1u << t) : 0u;
             float z[NC];
             float mx = -3.0e38f;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 z[c] = hy * r0[c] + ly * r1[c];
-                if (c < d.n_class) mx = fmaxf(mx, z[c]);
+                mx = fmaxf(mx, z[c]);
             }
             float se = 0.f, zt = 0.f;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                zt = (c == t) ? z[c] : zt;
-                const float e = (c < d.n_class) ? __expf(z[c] - mx) : 0.f;
+                zt = fmaf((float)((tm >> c) & 1u), z[c], zt);
+                const float e = __expf(z[c] - mx);
                 z[c] = e;
                 se += e;
             }
@@ -98,7 +122,7 @@ __global__ __launch_bounds__(256) void upce_kernel(const dsaspp_ce_desc d) {
             const float lse = mx + __logf(se);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const float gcl = z[c] * inv - ((c == t) ? live : 0.f);
+                const float gcl = fmaf(z[c], inv, -live * (float)((tm >> c) & 1u));
                 g0[c] = fmaf(hy, gcl, g0[c]);
                 g1[c] = fmaf(ly, gcl, g1[c]);
             }
@@ -115,23 +139,32 @@ __global__ __launch_bounds__(256) void upce_kernel(const dsaspp_ce_desc d) {
         float dummy;
         src_index(max(8 * ci - 4, 0), w, cx0, cx1, dummy);
     }
-    float* G = d.dlogits + (int64_t)n * h * w * d.ldl;
+    // tile-local pixel coordinates: the tile's first low-resolution pixel is (by*UP_TCY - 1, bx*UP_TCX - 1)
+    const int oy = by * UP_TCY - 1, ox = bx * UP_TCX - 1;
+    const int l00 = ((y0 - oy) * PX + (cx0 - ox)) * CS, l01 = ((y0 - oy) * PX + (cx1 - ox)) * CS;
+    const int l10 = ((y1 - oy) * PX + (cx0 - ox)) * CS, l11 = ((y1 - oy) * PX + (cx1 - ox)) * CS;
+    __syncthreads();                               // tile zeroed
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        float a00 = hx * g0[c], a01 = lx * g0[c], a10 = hx * g1[c], a11 = lx * g1[c];
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
-            a00 += __shfl_xor(a00, o, 64);
-            a01 += __shfl_xor(a01, o, 64);
-            a10 += __shfl_xor(a10, o, 64);
-            a11 += __shfl_xor(a11, o, 64);
+        const float a00 = row8_sum(hx * g0[c]), a01 = row8_sum(lx * g0[c]);
+        const float a10 = row8_sum(hx * g1[c]), a11 = row8_sum(lx * g1[c]);
+        // the 4*n_class additions of the cell, spread over its 8 lanes
+        if (cell_ok && (EXACT || c < d.n_class) && (c & 7) == lane8) {
+            atomicAdd(gt + l00 + c, a00);
+            atomicAdd(gt + l01 + c, a01);
+            atomicAdd(gt + l10 + c, a10);
+            atomicAdd(gt + l11 + c, a11);
         }
-        // spread the 4*n_class atomics of the cell over its 8 lanes
-        if (cell_ok && c < d.n_class && (c & 7) == lane8) {
-            atomicAdd(G + ((int64_t)y0 * w + cx0) * d.ldl + c, a00);
-            atomicAdd(G + ((int64_t)y0 * w + cx1) * d.ldl + c, a01);
-            atomicAdd(G + ((int64_t)y1 * w + cx0) * d.ldl + c, a10);
-            atomicAdd(G + ((int64_t)y1 * w + cx1) * d.ldl + c, a11);
+    }
+    __syncthreads();
+    float* G = d.dlogits + (int64_t)n * h * w * d.ldl;
+    for (int i = tid; i < PY * PX * 32; i += 256) {
+        const int c = i & 31, pix = i >> 5;
+        const int py = pix / PX, px = pix - py * PX;
+        const int gy = oy + py, gx = ox + px;
+        if (c < NC && (EXACT || c < d.n_class) && gy >= 0 && gy < h && gx >= 0 && gx < w) {
+            const float v = gt[pix * CS + c];
+            if (v != 0.f) atomicAdd(G + ((int64_t)gy * w + gx) * d.ldl + c, v);
         }
     }
     // loss / count: wave reduce, one atomic pair per wave
@@ -267,11 +300,11 @@ int check_ce(const dsaspp_ce_desc* d, const char* who) {
 extern "C" int dsaspp_upsample8_ce(const dsaspp_ce_desc* d, dsaspp_stream_t stream) {
     if (int rc = check_ce(d, "upsample8_ce")) return rc;
     DS_REQUIRE(d->logits && d->labels, "upsample8_ce: null tensor");
-    const int64_t ncell = (int64_t)d->n_img * (d->h + 1) * (d->w + 1);
-    const int64_t blocks = (ncell * 8 + 255) / 256;
+    const int tiles_x = (d->w + 1 + UP_TCX - 1) / UP_TCX, tiles_y = (d->h + 1 + UP_TCY - 1) / UP_TCY;
+    const int64_t blocks = (int64_t)d->n_img * tiles_x * tiles_y;
     DS_REQUIRE(blocks < (1ll << 31), "upsample8_ce: grid too large");
-    if (d->n_class <= 19) hipLaunchKernelGGL(upce_kernel<19>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d);
-    else hipLaunchKernelGGL(upce_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d);
+    if (d->n_class == 19) hipLaunchKernelGGL((upce_kernel<19, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((upce_kernel<32, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d, tiles_x, tiles_y);
     DS_LAUNCH_CHECK("upsample8_ce");
     return 0;
 }
