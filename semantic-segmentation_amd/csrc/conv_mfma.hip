@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
     };
 
     uint4 areg[AR], wreg[WR];
-    bool lval[AR];                      // validity of the chunks held in areg
+    bool lval[AR], wval[WR];            // validity of the chunks held in areg / wreg
     int lc = 0;                         // channel of the chunks held in areg (for the prologue tables)
     int tap = 0, c0 = 0;                // position of the next K-step to load
 
@@ -134,10 +134,10 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
         const int ko = cvalid ? tap * cin + c : 0;
 #pragma unroll
         for (int i = 0; i < WR; ++i) {
-            uint4 v = *reinterpret_cast<const uint4*>(w_ptr[i] + ko);
-            const bool ok = w_ok[i] && cvalid;
-            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-            wreg[i] = v;
+            // raw load only: touching the value here would make the wave wait for it before the MFMAs of the
+            // step in progress; out-of-range rows / the K tail are zeroed when the chunk goes to LDS
+            wreg[i] = *reinterpret_cast<const uint4*>(w_ptr[i] + ko);
+            wval[i] = w_ok[i] && cvalid;
         }
         lc = co;
         c0 += BK;
@@ -184,7 +184,10 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
             const int idx = tid + NT * i;
             if (idx < WCH) {
                 const int row = idx >> 3;
-                *reinterpret_cast<uint4*>(Ws + row * 128 + ((ck ^ swz8(row)) << 4)) = wreg[i];
+                uint4 v = wreg[i];
+                const bool ok = wval[i];
+                v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+                *reinterpret_cast<uint4*>(Ws + row * 128 + ((ck ^ swz8(row)) << 4)) = v;
             }
         }
     };
