@@ -12,6 +12,10 @@
 // layers a block instead owns the three taps of one filter row (RT = 3): a K-step of 64 pixels lies
 // inside one image row, so the three horizontally shifted input windows are one staged tile of
 // 64 + 2*dilation pixels read at three row offsets, and the dz tile is shared as well.
+// The fp32 atomics of the epilogue execute at the memory side (about 1.3 TB/s chip-wide) and their volume is
+// (pixel splits) x (weight bytes).  KG = 2 halves it at equal occupancy: a block is two wave groups with private
+// staging buffers that take alternate K-steps of the block's pixel range; the second group's accumulators meet
+// the first group's through LDS and only one set goes out.
 #include "common.h"
 
 namespace {
@@ -32,11 +36,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const int hal
 
 constexpr int RT_MAXDIL = 8;   // largest dilation of the shared-row form (tile rows = BKP + 2*dilation)
 
-template <int BQ, int BC, int WQ, int WC, int PRO, int RT>
-__global__ __launch_bounds__(64 * WQ * WC, (WQ * WC == 8) ? 4 : 2) void wgrad_kernel(const dsaspp_wgrad_desc d, const int M,
+template <int BQ, int BC, int WQ, int WC, int PRO, int RT, int KG>
+__global__ __launch_bounds__(64 * WQ * WC * KG, (WQ * WC == 8) ? 4 : 2) void wgrad_kernel(const dsaspp_wgrad_desc d, const int M,
                                                                                    const int nQ, const int nC,
                                                                                    const int chunk) {
-    constexpr int NW = WQ * WC, NT = 64 * NW;
+    constexpr int NW = WQ * WC, NT = 64 * NW;        // waves / threads of one K group
+    constexpr int NTB = NT * KG;                     // threads of the block
     constexpr int ZS = BQ + PADE, XS = BC + PADE;               // LDS row strides in elements
     constexpr int XROWS = (RT == 3) ? BKP + 2 * RT_MAXDIL : BKP;   // staged input rows (upper bound)
     constexpr int Z_BYTES = BKP * ZS * 2, X_BYTES = XROWS * XS * 2;
@@ -49,11 +54,13 @@ __global__ __launch_bounds__(64 * WQ * WC, (WQ * WC == 8) ? 4 : 2) void wgrad_ke
     static_assert(TQ % 16 == 0 && TC % 16 == 0, "wave tile");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Zs = smem;
-    unsigned char* Xs = smem + Z_BYTES;
-    float* tab = reinterpret_cast<float*>(smem + Z_BYTES + X_BYTES);   // scale[BC], shift[BC]
+    const int grp = (KG > 1) ? (int)(threadIdx.x / NT) : 0;            // K group of this wave
+    const int tid = (KG > 1) ? (int)(threadIdx.x % NT) : (int)threadIdx.x;   // thread index inside the group
+    unsigned char* Zs = smem + grp * (Z_BYTES + X_BYTES);
+    unsigned char* Xs = Zs + Z_BYTES;
+    float* tab = reinterpret_cast<float*>(smem + KG * (Z_BYTES + X_BYTES));   // scale[BC], shift[BC]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     // blocks that share a pixel range (and so the dz tile) get neighbouring logical ids -> same XCD / L2
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int ct = bid % nC; bid /= nC;
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(64 * WQ * WC, (WQ * WC == 8) ? 4 : 2) void wgrad_ke
     const float relu_floor = d.in_relu ? 0.f : -3.0e38f;
 
     if (PRO != 0 && has_scale) {
-        for (int c = tid; c < BC; c += NT) {
+        for (int c = threadIdx.x; c < BC; c += NTB) {
             const bool ok = c_base + c < cin;
             tab[c] = ok ? d.in_scale[c_base + c] : 0.f;
             tab[BC + c] = ok ? d.in_shift[c_base + c] : 0.f;
@@ -192,32 +199,58 @@ __global__ __launch_bounds__(64 * WQ * WC, (WQ * WC == 8) ? 4 : 2) void wgrad_ke
             for (int j = 0; j < MC; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int tstride = (RT == 3) ? d.dil * XS * 2 : 0;     // byte offset between the windows of neighbouring taps
 
-    if (ksteps > 0) {
-        gload(0);
+    // group g takes K-steps g, g+KG, ...; barriers are block-wide, so both groups run the same trip count
+    {
+        const int trips = (ksteps + KG - 1) / KG;
+        if (grp < ksteps) gload(grp);
         __syncthreads();      // scale/shift table visible
-        for (int s = 0; s < ksteps; ++s) {
-            sstore();
+        for (int it = 0; it < trips; ++it) {
+            const int s = it * KG + grp;
+            const bool active = s < ksteps;
+            if (active) sstore();
             __syncthreads();
-            if (s + 1 < ksteps) gload(s + 1);
+            if (s + KG < ksteps) gload(s + KG);
+            if (active) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 zf[MQ];
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 zf[MQ];
 #pragma unroll
-                for (int i = 0; i < MQ; ++i) zf[i] = tr_frag(Zs + zfrag + (ks * 32 * ZS + i * 16) * 2, 4 * ZS * 2);
+                    for (int i = 0; i < MQ; ++i) zf[i] = tr_frag(Zs + zfrag + (ks * 32 * ZS + i * 16) * 2, 4 * ZS * 2);
 #pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    bf16x8 xf[MC];
+                    for (int t = 0; t < RT; ++t) {
+                        bf16x8 xf[MC];
 #pragma unroll
-                    for (int j = 0; j < MC; ++j) xf[j] = tr_frag(Xs + xfrag + t * tstride + (ks * 32 * XS + j * 16) * 2, 4 * XS * 2);
+                        for (int j = 0; j < MC; ++j) xf[j] = tr_frag(Xs + xfrag + t * tstride + (ks * 32 * XS + j * 16) * 2, 4 * XS * 2);
 #pragma unroll
-                    for (int i = 0; i < MQ; ++i)
+                        for (int i = 0; i < MQ; ++i)
 #pragma unroll
-                        for (int j = 0; j < MC; ++j)
-                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[i], xf[j], acc[t][i][j], 0, 0, 0);
+                            for (int j = 0; j < MC; ++j)
+                                acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[i], xf[j], acc[t][i][j], 0, 0, 0);
+                    }
                 }
             }
             __syncthreads();
         }
+    }
+    if (KG > 1) {
+        // the second group's partial sums meet the first group's in LDS (same thread index = same outputs)
+        f32x4* red = reinterpret_cast<f32x4*>(smem);
+        if (grp == 1) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int i = 0; i < MQ; ++i)
+#pragma unroll
+                    for (int j = 0; j < MC; ++j) red[((t * MQ + i) * MC + j) * NT + tid] = acc[t][i][j];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int i = 0; i < MQ; ++i)
+#pragma unroll
+                for (int j = 0; j < MC; ++j) acc[t][i][j] += red[((t * MQ + i) * MC + j) * NT + tid];
     }
 
     // ---- epilogue: acc[i][j][r] is (q = q0 + i*16 + fc*4 + r, c = c0 + j*16 + fr)
@@ -243,20 +276,25 @@ __global__ __launch_bounds__(64 * WQ * WC, (WQ * WC == 8) ? 4 : 2) void wgrad_ke
 
 template <int BQ, int BC, int WQ, int WC, int PRO, int RT>
 int launch_rt(const dsaspp_wgrad_desc& d, hipStream_t s) {
+    constexpr int KG = (RT == 3) ? 2 : 1;      // two lock-stepped 8-wave groups lose more overlap than the atomics cost
+    constexpr int MQ = BQ / WQ / 16, MC = BC / WC / 16;
     const int M = d.n_img * d.H * d.W;
     const int nQ = (d.cout + BQ - 1) / BQ, nC = (d.cin + BC - 1) / BC;
     const int base_blocks = nQ * nC * (d.taps / RT);
     int ksplit = d.ksplit;
     const int max_split = (M + 4 * BKP - 1) / (4 * BKP);   // at least 4 K-steps per block
-    if (ksplit <= 0) ksplit = 512 / base_blocks;           // one round of resident blocks: the fewest atomic epilogues
+    if (ksplit <= 0) ksplit = (512 / KG) / base_blocks;    // one round of resident blocks: the fewest atomic epilogues
     if (ksplit > max_split) ksplit = max_split;
     if (ksplit < 1) ksplit = 1;
     int chunk = (M + ksplit - 1) / ksplit;
     chunk = (chunk + BKP - 1) / BKP * BKP;
     ksplit = (M + chunk - 1) / chunk;
-    const size_t lds = (size_t)BKP * (BQ + PADE) * 2 + (size_t)(RT == 3 ? BKP + 2 * RT_MAXDIL : BKP) * (BC + PADE) * 2 +
-                       ((PRO != 0 && d.in_scale) ? (size_t)BC * 8 : 0);
-    auto kern = wgrad_kernel<BQ, BC, WQ, WC, PRO, RT>;
+    size_t lds = KG * ((size_t)BKP * (BQ + PADE) * 2 + (size_t)(RT == 3 ? BKP + 2 * RT_MAXDIL : BKP) * (BC + PADE) * 2) +
+                 ((PRO != 0 && d.in_scale) ? (size_t)BC * 8 : 0);
+    const size_t red = (KG > 1) ? (size_t)RT * MQ * MC * 16 * 64 * WQ * WC : 0;      // accumulator exchange
+    if (red > lds) lds = red;
+    DS_REQUIRE(lds <= 160 * 1024, "conv_wgrad: LDS request %zu too large", lds);
+    auto kern = wgrad_kernel<BQ, BC, WQ, WC, PRO, RT, KG>;
     if (lds > 64 * 1024) {
         static thread_local bool done = false;
         if (!done) {
@@ -264,7 +302,7 @@ int launch_rt(const dsaspp_wgrad_desc& d, hipStream_t s) {
             done = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(base_blocks * ksplit), dim3(64 * WQ * WC), lds, s, d, M, nQ, nC, chunk);
+    hipLaunchKernelGGL(kern, dim3(base_blocks * ksplit), dim3(64 * WQ * WC * KG), lds, s, d, M, nQ, nC, chunk);
     DS_LAUNCH_CHECK("conv_wgrad");
     return 0;
 }
