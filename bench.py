@@ -65,7 +65,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=4, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    ap.add_argument('--force-reducer', action='store_true',
+                    help='one rank, but run the bucketed all-reduce path of N > 1 (rehearsal)')
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=2048)
     ap.add_argument('--model', default='DenseASPP161')
@@ -82,8 +84,9 @@ def main():
                          % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 or args.force_reducer:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     import importlib
@@ -101,7 +104,7 @@ def main():
     gen = torch.Generator(device=device)
     gen.manual_seed(99 + rank)
     eng = model.engine(B, H, W, True)
-    reducer = GradReducer(model, eng) if world > 1 else None
+    reducer = GradReducer(model, eng, always=args.force_reducer) if (world > 1 or args.force_reducer) else None
     model.refresh_weights()
 
     def step():
@@ -188,7 +191,7 @@ def main():
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_reducer:
         dist.destroy_process_group()
 
 

@@ -612,6 +612,7 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
                 case 1: return launch<128, 192, 2, 4>(d, s);
                 case 2: return launch<128, 128, 2, 4>(d, s);
                 case 5: return launch<64, 128, 1, 4>(d, s);
+                case 6: return launch<64, 192, 1, 4>(d, s);
                 case 8: return launch<128, 64, 2, 2>(d, s);
                 default: break;
             }

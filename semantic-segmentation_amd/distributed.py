@@ -14,19 +14,24 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, model, engine, bucket_mb=25.0, group=None):
+    def __init__(self, model, engine, bucket_mb=25.0, group=None, always=False):
         self.model, self.engine, self.group = model, engine, group
+        self.always = always             # issue the collectives even in a one-rank group (rehearsal of the N > 1 path)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         gflat = model._gflat
         n = gflat.numel()
         ops = engine._bwd.keepalive if hasattr(engine._bwd, 'keepalive') else engine._bwd.ops
         # last op index that writes each arena entry
+        import bisect
+        entries = sorted(model.arena.entries, key=lambda e: e.off)
+        starts = [e.off for e in entries]
         last_write = {}
         for i, (kind, f) in enumerate(ops):
             for k, v in f.items():
                 if hasattr(v, 't') and v.t is gflat:
-                    last_write[v.off] = i
-        entries = sorted(model.arena.entries, key=lambda e: e.off)
+                    # a descriptor may point into the middle of an entry (channel sub-range of a BatchNorm gradient)
+                    j = bisect.bisect_right(starts, v.off) - 1
+                    last_write[starts[j]] = i
         per_bucket = max(1, int(bucket_mb * 1024 * 1024 / 4))
         self.buckets = []          # (lo, hi, ready_op_index), from the end of the arena to its start
         hi = n
@@ -61,7 +66,7 @@ class GradReducer:
             if end > pos:
                 eng._bwd.run(first=pos, last=end)
                 pos = end
-            if self.world > 1:
+            if self.world > 1 or self.always:
                 handles.append(dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         if pos < self.n_ops:
             eng._bwd.run(first=pos, last=self.n_ops)
