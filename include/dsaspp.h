@@ -59,7 +59,7 @@ typedef struct dsaspp_conv_desc {
     const void* w;            /* bf16 [cout][taps*cin] */
     const float* in_scale;    /* [cin] or NULL (identity) */
     const float* in_shift;    /* [cin] or NULL */
-    int32_t in_relu;
+    int32_t in_relu;          /* 0 none, 1 ReLU, 2 ReLU6 (1x1 forward form only) */
     const float* in_mask;     /* [n_img][in_mask_ld] per-image channel multiplier or NULL */
     int32_t in_mask_ld;
     const float* bias;        /* [cout] or NULL */
@@ -187,14 +187,16 @@ int dsaspp_bn_bwd_finalize(const dsaspp_bn_bwd_desc* d, dsaspp_stream_t stream);
  * Row-wise (pixel x channel) streaming kernels, NHWC, 8 channels per lane.
  */
 
-/* y = relu?(x*scale+shift) -> bf16, optional statistics of the stored values
- * (features.norm5 + the in-place ReLU heading ASPP_3). */
+/* y = act(x*scale+shift + res) -> bf16, optional statistics of the stored values
+ * (features.norm5 + the in-place ReLU heading ASPP_3; the BatchNorm closing a MobileNetV2
+ * inverted-residual block and its skip connection).  relu: 0 none, 1 ReLU, 2 ReLU6. */
 typedef struct dsaspp_bnact_desc {
     int64_t M; int32_t C;
     const void* x; int32_t ldx;
     const float* scale; const float* shift; int32_t relu;
     void* y; int32_t ldy;
     float* stat_acc;          /* [R][2*C] or NULL */
+    const void* res; int32_t ldres;   /* bf16 [M][ldres] added after the affine map, or NULL */
 } dsaspp_bnact_desc;
 int dsaspp_bn_act(const dsaspp_bnact_desc* d, dsaspp_stream_t stream);
 
@@ -270,6 +272,39 @@ typedef struct dsaspp_maxpool_desc {
 } dsaspp_maxpool_desc;
 int dsaspp_maxpool3s2_fwd(const dsaspp_maxpool_desc* d, dsaspp_stream_t stream);
 int dsaspp_maxpool3s2_bwd(const dsaspp_maxpool_desc* d, dsaspp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * MobileNetV2 trunk of MobileNetDenseASPP (reference: cfgs/MobileNetDenseASPP.py:1-8 configures
+ * it; constructor call site graph_seg_test.py:129).  Pointwise convolutions run through
+ * dsaspp_conv_fwd; these two cover the layers that are not GEMM shaped.
+ */
+
+/* Stem: 3x3 stride-2 pad-1 convolution of the NCHW fp32 network input (3 channels) to raw
+ * (pre-BatchNorm) bf16 NHWC rows [N*(H/2)*(W/2)][ldy]; H and W even.
+ * w: bf16 [cout][27], K order (ky, kx, ci); cout a multiple of 8, at most 64. */
+typedef struct dsaspp_stem3_desc {
+    int32_t n_img, H, W;      /* input image size */
+    const float* x;
+    const void* w;
+    int32_t cout;
+    void* y; int32_t ldy;
+} dsaspp_stem3_desc;
+int dsaspp_stem3x3s2(const dsaspp_stem3_desc* d, dsaspp_stream_t stream);
+
+/* Depthwise 3x3 convolution, stride 1 or 2, dilation dil, zero padding dil (applied AFTER the
+ * prologue), with the producer's BatchNorm + activation fused in front:
+ *   a = act(x*in_scale + in_shift)   (in_relu: 0 none, 1 ReLU, 2 ReLU6; identity affine when NULL)
+ *   y[n][ho][wo][c] = sum_{ky,kx} w[c][ky*3+kx] * a[n][ho*stride+(ky-1)*dil][wo*stride+(kx-1)*dil][c]
+ * Output geometry ((H-1)/stride+1) x ((W-1)/stride+1); raw (pre-BatchNorm) bf16 NHWC. */
+typedef struct dsaspp_dw_desc {
+    int32_t n_img, H, W, C;   /* input geometry; C a multiple of 8 */
+    int32_t stride, dil;
+    const void* x; int32_t ldx;
+    const float* in_scale; const float* in_shift; int32_t in_relu;
+    const void* w;            /* bf16 [C][9] */
+    void* y; int32_t ldy;
+} dsaspp_dw_desc;
+int dsaspp_dwconv3x3(const dsaspp_dw_desc* d, dsaspp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Bilinear x8 upsample (align_corners=False) fused with softmax cross-entropy
@@ -363,7 +398,7 @@ enum {
     DSASPP_OP_BN_ACT, DSASPP_OP_GRAD_EXTRACT, DSASPP_OP_BN_BWD_APPLY, DSASPP_OP_AVGPOOL_FWD,
     DSASPP_OP_AVGPOOL_BWD, DSASPP_OP_IM2COL, DSASPP_OP_MAXPOOL_FWD, DSASPP_OP_MAXPOOL_BWD,
     DSASPP_OP_UPCE, DSASPP_OP_CE_FINALIZE, DSASPP_OP_UP_FWD, DSASPP_OP_UP_BWD, DSASPP_OP_UP_ARGMAX,
-    DSASPP_OP_MEMSET, DSASPP_OP_COPY2D, DSASPP_OP_COPY2D_BF16
+    DSASPP_OP_MEMSET, DSASPP_OP_COPY2D, DSASPP_OP_COPY2D_BF16, DSASPP_OP_STEM3, DSASPP_OP_DWCONV
 };
 dsaspp_program* dsaspp_program_create(void);
 void dsaspp_program_destroy(dsaspp_program* p);

@@ -83,6 +83,8 @@ up_desc = STRUCTS['dsaspp_up_desc']
 adam_desc = STRUCTS['dsaspp_adam_desc']
 wt_entry = STRUCTS['dsaspp_wt_entry']
 generic_desc = STRUCTS['dsaspp_generic_desc']
+stem3_desc = STRUCTS['dsaspp_stem3_desc']
+dw_desc = STRUCTS['dsaspp_dw_desc']
 
 # op name -> (program op code, descriptor struct, direct entry point)
 OPS = {
@@ -106,6 +108,8 @@ OPS = {
     'memset': (ENUMS['DSASPP_OP_MEMSET'], generic_desc, None),
     'copy2d': (ENUMS['DSASPP_OP_COPY2D'], generic_desc, None),
     'copy2d_bf16': (ENUMS['DSASPP_OP_COPY2D_BF16'], generic_desc, None),
+    'stem3': (ENUMS['DSASPP_OP_STEM3'], stem3_desc, 'dsaspp_stem3x3s2'),
+    'dwconv': (ENUMS['DSASPP_OP_DWCONV'], dw_desc, 'dsaspp_dwconv3x3'),
 }
 
 _lib = None

@@ -84,9 +84,10 @@ class HipBackend:
         ar = model.arena
         if cast:
             _lib.check(lib.dsaspp_cast_bf16(model._flat.data_ptr(), model._w16.data_ptr(), ar.size, stream))
-        e0 = ar.by_name['features.conv0.weight']
-        _lib.check(lib.dsaspp_copy2d_f32_bf16(model._flat.data_ptr() + 4 * e0.off, S.STEM_K, model._w0_16.data_ptr(),
-                                              S.STEM_KPAD, e0.rows, S.STEM_K, S.STEM_KPAD, stream))
+        e0 = ar.by_name.get('features.conv0.weight')
+        if e0 is not None:      # 7x7 stem of the DenseNet trunk: rows padded 147 -> 160 for the im2col GEMM
+            _lib.check(lib.dsaspp_copy2d_f32_bf16(model._flat.data_ptr() + 4 * e0.off, S.STEM_K, model._w0_16.data_ptr(),
+                                                  S.STEM_KPAD, e0.rows, S.STEM_K, S.STEM_KPAD, stream))
         if model._wt_table is None:
             ents = [e for e in ar.entries if e.kind == 'conv']
             tab = (_lib.wt_entry * len(ents))()

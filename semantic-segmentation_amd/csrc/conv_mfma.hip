@@ -66,6 +66,7 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
         }
     }
     const float relu_floor = d.in_relu ? 0.f : -3.0e38f;
+    const float relu_ceil = (d.in_relu == 2) ? 6.f : 3.0e38f;     // ReLU6: general prologue (PRO == 2) only
 
     // ---- per-thread staging coordinates: chunk column ck of rows (tid>>3) + RSTEP*i
     const int ck = tid & 7;
@@ -166,6 +167,10 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], relu_floor);
+                if (PRO == 2) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fminf(f[e], relu_ceil);
+                }
                 if (PRO == 2 && d.in_mask) {
                     float mk[8];
                     load8f(d.in_mask + (int64_t)a_n[i] * d.in_mask_ld + lc, mk);
@@ -540,7 +545,7 @@ int launch_mode(const dsaspp_conv_desc& d, hipStream_t s) {
 
 template <int BP, int BQ, int WP, int WQ>
 int launch(const dsaspp_conv_desc& d, hipStream_t s) {
-    const int pro = d.in_mask ? 2 : d.in_scale ? 1 : d.in_relu ? 2 : 0;
+    const int pro = (d.in_mask || d.in_relu == 2) ? 2 : d.in_scale ? 1 : d.in_relu ? 2 : 0;
     const int epi = d.g ? 2 : ((d.epi_relu || d.s_acc) ? 1 : 0);
     if (epi == 0) {
         if (pro == 0) return launch_mode<BP, BQ, WP, WQ, 0, 0>(d, s);
@@ -568,6 +573,7 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
     DS_REQUIRE(d.x && d.w, "conv_fwd: null operand");
     DS_REQUIRE(((uintptr_t)d.x & 15) == 0 && ((uintptr_t)d.w & 15) == 0, "conv_fwd: operands must be 16-byte aligned");
     DS_REQUIRE((d.in_scale == nullptr) == (d.in_shift == nullptr), "conv_fwd: in_scale/in_shift must come together");
+    DS_REQUIRE(d.in_relu >= 0 && d.in_relu <= 2 && (d.in_relu != 2 || d.taps == 1), "conv_fwd: in_relu must be 0, 1, or 2 (ReLU6, 1x1 only)");
     if (d.g) {
         DS_REQUIRE(d.ldg % 8 == 0 && d.ldg >= d.cout && ((uintptr_t)d.g & 15) == 0, "conv_fwd: bad gradient slab stride/alignment");
     } else {

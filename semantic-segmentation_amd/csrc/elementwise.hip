@@ -93,16 +93,23 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const dsaspp_bnact_desc d) 
     if (act && d.scale) { load8f(d.scale + c, sc); load8f(d.shift + c, sh); }
     const u16* xg = reinterpret_cast<const u16*>(d.x);
     u16* yg = reinterpret_cast<u16*>(d.y);
+    const u16* rg = reinterpret_cast<const u16*>(d.res);
+    const float lo = d.relu ? 0.f : -3.0e38f, hi = (d.relu == 2) ? 6.f : 3.0e38f;
     if (act) {
         for (int64_t m = (int64_t)blockIdx.y * RB + ry; m < d.M; m += (int64_t)gridDim.y * RB) {
             const uint4 v = *reinterpret_cast<const uint4*>(xg + m * d.ldx + c);
             float f[8];
             unpack8(v, f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                f[e] = fmaf(f[e], sc[e], sh[e]);
-                if (d.relu) f[e] = fmaxf(f[e], 0.f);
+            for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+            if (rg) {
+                float r[8];
+                unpack8(*reinterpret_cast<const uint4*>(rg + m * d.ldres + c), r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += r[e];
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(f[e], lo), hi);
             const uint4 o = pack8(f);
             *reinterpret_cast<uint4*>(yg + m * d.ldy + c) = o;
             if (d.stat_acc) {
@@ -474,6 +481,8 @@ extern "C" int dsaspp_bn_bwd_finalize(const dsaspp_bn_bwd_desc* d, dsaspp_stream
 extern "C" int dsaspp_bn_act(const dsaspp_bnact_desc* d, dsaspp_stream_t stream) {
     DS_REQUIRE(d && d->M > 0 && d->C > 0 && d->C % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0, "bn_act: bad descriptor");
     DS_REQUIRE(d->x && d->y, "bn_act: null tensor");
+    DS_REQUIRE(d->relu >= 0 && d->relu <= 2, "bn_act: relu must be 0, 1 or 2");
+    if (d->res) DS_REQUIRE(d->ldres % 8 == 0 && d->ldres >= d->C && ((uintptr_t)d->res & 15) == 0, "bn_act: bad residual stride/alignment");
     ROW_DISPATCH(bn_act_kernel, d->C, d->M, *d, (hipStream_t)stream);
     DS_LAUNCH_CHECK("bn_act");
     return 0;

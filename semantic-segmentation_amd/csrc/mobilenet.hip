@@ -1,0 +1,172 @@
+// MobileNetV2-trunk kernels that are not GEMM shaped: the 3x3/2 stem on the 3-channel image and the
+// depthwise (dilated, optionally strided) 3x3 convolution.  Both are bandwidth-bound streaming kernels:
+// a lane owns 8 consecutive channels of one output pixel (one 16-byte NHWC chunk), consecutive lanes own
+// consecutive chunks of the same pixel and then the next pixel, so every store instruction of a wave covers
+// one contiguous run of memory and the nine tap loads are contiguous runs shifted by the tap offset.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- stem: 3x3 stride 2, 3 -> cout channels
+// Weights (cout x 27, bf16) are expanded to fp32 in LDS as [27][cout]; a lane reads the 27 input values of
+// its pixel (shared by the cout/8 lanes of that pixel: broadcast loads) and 8 output channels of weights.
+__global__ __launch_bounds__(256) void stem3_kernel(const dsaspp_stem3_desc d, const int Ho, const int Wo, const int cg,
+                                                    const int total) {
+    __shared__ float ws[27 * 64];
+    const int cout = d.cout;
+    const u16* wg = reinterpret_cast<const u16*>(d.w);
+    for (int i = threadIdx.x; i < 27 * cout; i += 256) {
+        const int k = i / cout, c = i - k * cout;
+        ws[i] = __uint_as_float((uint32_t)wg[c * 27 + k] << 16);
+    }
+    __syncthreads();
+    const int H = d.H, W = d.W;
+    const int64_t plane = (int64_t)H * W;
+    u16* yg = reinterpret_cast<u16*>(d.y);
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int m = idx / cg, g = idx - m * cg;
+        const int n = m / (Ho * Wo);
+        const int rem = m - n * (Ho * Wo);
+        const int ho = rem / Wo, wo = rem - ho * Wo;
+        const float* xn = d.x + (int64_t)n * 3 * plane;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int hi = 2 * ho - 1 + ky;
+            const bool hok = (unsigned)hi < (unsigned)H;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int wi = 2 * wo - 1 + kx;
+                const bool ok = hok && (unsigned)wi < (unsigned)W;
+                const int64_t off = ok ? (int64_t)hi * W + wi : 0;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    // the network input is rounded to bf16 like every other MFMA/VALU operand of the path
+                    const float v = ok ? bf_round(xn[ci * plane + off]) : 0.f;
+                    float w8[8];
+                    load8f(ws + ((ky * 3 + kx) * 3 + ci) * cout + g * 8, w8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(v, w8[e], acc[e]);
+                }
+            }
+        }
+        *reinterpret_cast<uint4*>(yg + (int64_t)m * d.ldy + g * 8) = pack8(acc);
+    }
+}
+
+// ---------------------------------------------------------------- depthwise 3x3
+// The grid is sized so that (threads in the grid) is a multiple of the channel-group count: a lane keeps the
+// same 8 channels for its whole pixel loop and holds their 72 weights and the prologue tables in registers.
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const dsaspp_dw_desc d, const int Ho, const int Wo, const int cg,
+                                                        const int total) {
+    const int tid0 = blockIdx.x * 256 + threadIdx.x;
+    const int nthreads = gridDim.x * 256;
+    const int g = tid0 % cg, c = g * 8;
+    float w[9][8], sc[8], sh[8];
+    {
+        const u16* wg = reinterpret_cast<const u16*>(d.w) + (int64_t)c * 9;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) w[t][e] = __uint_as_float((uint32_t)wg[e * 9 + t] << 16);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+    const bool affine = d.in_scale != nullptr;
+    if (affine) { load8f(d.in_scale + c, sc); load8f(d.in_shift + c, sh); }
+    const bool pro = affine || d.in_relu;
+    const float lo = d.in_relu ? 0.f : -3.0e38f, hi = (d.in_relu == 2) ? 6.f : 3.0e38f;
+    const int H = d.H, W = d.W, st = d.stride, dil = d.dil;
+    const u16* xg = reinterpret_cast<const u16*>(d.x) + c;
+    u16* yg = reinterpret_cast<u16*>(d.y) + c;
+    for (int idx = tid0; idx < total; idx += nthreads) {
+        const int m = idx / cg;
+        const int n = m / (Ho * Wo);
+        const int rem = m - n * (Ho * Wo);
+        const int ho = rem / Wo, wo = rem - ho * Wo;
+        uint4 v[9];
+        bool ok[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int hi_ = ho * st + (ky - 1) * dil;
+            const bool hok = (unsigned)hi_ < (unsigned)H;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int wi = wo * st + (kx - 1) * dil;
+                const bool o = hok && (unsigned)wi < (unsigned)W;
+                ok[ky * 3 + kx] = o;
+                const int64_t pix = o ? ((int64_t)n * H + hi_) * W + wi : 0;
+                v[ky * 3 + kx] = *reinterpret_cast<const uint4*>(xg + pix * d.ldx);   // always a mapped address
+            }
+        }
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float f[8];
+            unpack8(v[t], f);
+            if (pro) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = bf_round(fminf(fmaxf(fmaf(f[e], sc[e], sh[e]), lo), hi));
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(ok[t] ? f[e] : 0.f, w[t][e], acc[e]);
+        }
+        *reinterpret_cast<uint4*>(yg + (int64_t)m * d.ldy) = pack8(acc);
+    }
+}
+
+int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
+
+// Number of 256-thread blocks: enough to fill the chip several times over, a multiple of `unit` so that
+// the grid-wide thread count is a multiple of the channel-group count.
+int grid_blocks(int64_t total, int cg) {
+    const int unit = cg / gcd_i(cg, 256);
+    int64_t want = (total + 255) / 256;
+    if (want > 8192) want = 8192;
+    if (want < 1) want = 1;
+    return (int)((want + unit - 1) / unit * unit);
+}
+
+}  // namespace
+
+extern "C" int dsaspp_stem3x3s2(const dsaspp_stem3_desc* dp, dsaspp_stream_t stream) {
+    DS_REQUIRE(dp != nullptr, "stem3x3s2: null descriptor");
+    const dsaspp_stem3_desc& d = *dp;
+    DS_REQUIRE(d.n_img > 0 && d.H > 0 && d.W > 0 && d.H % 2 == 0 && d.W % 2 == 0, "stem3x3s2: image size must be even (got %d x %d)", d.H, d.W);
+    DS_REQUIRE(d.cout > 0 && d.cout % 8 == 0 && d.cout <= 64, "stem3x3s2: cout must be a multiple of 8, at most 64 (got %d)", d.cout);
+    DS_REQUIRE(d.x && d.w && d.y, "stem3x3s2: null tensor");
+    DS_REQUIRE(d.ldy % 8 == 0 && d.ldy >= d.cout && ((uintptr_t)d.y & 15) == 0, "stem3x3s2: output stride/alignment");
+    const int Ho = d.H / 2, Wo = d.W / 2, cg = d.cout / 8;
+    const int64_t total = (int64_t)d.n_img * Ho * Wo * cg;
+    DS_REQUIRE(total < (1ll << 31) - (1 << 23), "stem3x3s2: too many output chunks");
+    int64_t nb = (total + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(stem3_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, d, Ho, Wo, cg, (int)total);
+    DS_LAUNCH_CHECK("stem3x3s2");
+    return 0;
+}
+
+extern "C" int dsaspp_dwconv3x3(const dsaspp_dw_desc* dp, dsaspp_stream_t stream) {
+    DS_REQUIRE(dp != nullptr, "dwconv3x3: null descriptor");
+    const dsaspp_dw_desc& d = *dp;
+    DS_REQUIRE(d.n_img > 0 && d.H > 0 && d.W > 0, "dwconv3x3: bad geometry %d x %d x %d", d.n_img, d.H, d.W);
+    DS_REQUIRE(d.C > 0 && d.C % 8 == 0, "dwconv3x3: C must be a positive multiple of 8 (got %d)", d.C);
+    DS_REQUIRE(d.stride == 1 || d.stride == 2, "dwconv3x3: stride must be 1 or 2 (got %d)", d.stride);
+    DS_REQUIRE(d.dil >= 1, "dwconv3x3: dilation must be >= 1 (got %d)", d.dil);
+    DS_REQUIRE(d.x && d.w && d.y, "dwconv3x3: null tensor");
+    DS_REQUIRE(d.ldx % 8 == 0 && d.ldx >= d.C && d.ldy % 8 == 0 && d.ldy >= d.C, "dwconv3x3: strides must be multiples of 8 and >= C");
+    DS_REQUIRE((((uintptr_t)d.x | (uintptr_t)d.y) & 15) == 0, "dwconv3x3: tensors must be 16-byte aligned");
+    DS_REQUIRE((d.in_scale == nullptr) == (d.in_shift == nullptr), "dwconv3x3: in_scale/in_shift must come together");
+    DS_REQUIRE(d.in_relu >= 0 && d.in_relu <= 2, "dwconv3x3: in_relu must be 0, 1 or 2");
+    const int Ho = (d.H - 1) / d.stride + 1, Wo = (d.W - 1) / d.stride + 1, cg = d.C / 8;
+    const int64_t total = (int64_t)d.n_img * Ho * Wo * cg;
+    DS_REQUIRE(total < (1ll << 31) - (1 << 22), "dwconv3x3: too many output chunks");
+    const int nb = grid_blocks(total, cg);
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, d, Ho, Wo, cg, (int)total);
+    DS_LAUNCH_CHECK("dwconv3x3");
+    return 0;
+}

@@ -35,6 +35,8 @@ union AnyDesc {
     dsaspp_ce_desc ce;
     dsaspp_up_desc up;
     dsaspp_generic_desc gen;
+    dsaspp_stem3_desc stem3;
+    dsaspp_dw_desc dw;
 };
 struct Op {
     int32_t kind;
@@ -67,6 +69,8 @@ size_t desc_size(int32_t op) {
         case DSASPP_OP_MEMSET:
         case DSASPP_OP_COPY2D:
         case DSASPP_OP_COPY2D_BF16: return sizeof(dsaspp_generic_desc);
+        case DSASPP_OP_STEM3: return sizeof(dsaspp_stem3_desc);
+        case DSASPP_OP_DWCONV: return sizeof(dsaspp_dw_desc);
         default: return 0;
     }
 }
@@ -177,6 +181,8 @@ extern "C" int dsaspp_program_run(dsaspp_program* p, int32_t first, int32_t last
                 rc = dsaspp_copy2d_f32_bf16((const float*)o.d.gen.src, o.d.gen.lds, o.d.gen.dst, o.d.gen.ldd, o.d.gen.rows,
                                             o.d.gen.cols, o.d.gen.dst_cols, s);
                 break;
+            case DSASPP_OP_STEM3: rc = dsaspp_stem3x3s2(&o.d.stem3, s); break;
+            case DSASPP_OP_DWCONV: rc = dsaspp_dwconv3x3(&o.d.dw, s); break;
             default: rc = dsaspp_set_error("program_run: unknown op %d at %d", o.kind, i);
         }
         if (timed) {

@@ -49,6 +49,26 @@ def _holder_aspp(cin, d0, d1, rate, bn_start):
     return m
 
 
+def _holder_ir(b):
+    """Inverted-residual block: Sequential indices 0/1 expand conv+BN, 3/4 depthwise conv+BN, 6/7 linear conv+BN."""
+    m = nn.Module()
+    m.conv = nn.Sequential(
+        nn.Conv2d(b.cin, b.hid, 1, bias=False), nn.BatchNorm2d(b.hid), nn.ReLU6(inplace=True),
+        nn.Conv2d(b.hid, b.hid, 3, b.stride, padding=b.dil, dilation=b.dil, groups=b.hid, bias=False),
+        nn.BatchNorm2d(b.hid), nn.ReLU6(inplace=True),
+        nn.Conv2d(b.hid, b.cout, 1, bias=False), nn.BatchNorm2d(b.cout))
+    return m
+
+
+def _holder_mobilenet(sp):
+    """MobileNetV2 trunk; parameter names features.features.<i>.* (trunk module holding a Sequential)."""
+    trunk = nn.Module()
+    layers = [nn.Sequential(nn.Conv2d(3, sp.c_stem, 3, 2, 1, bias=False), nn.BatchNorm2d(sp.c_stem), nn.ReLU6(inplace=True))]
+    layers += [_holder_ir(b) for b in sp.ir]
+    trunk.features = nn.Sequential(*layers)
+    return trunk
+
+
 class _LogitsFn(torch.autograd.Function):
     """Autograd bridge for the plain ``model(x)`` API (full-resolution logits)."""
 
@@ -86,11 +106,14 @@ class DenseASPP(nn.Module):
         cs = sp.c_stem
 
         feats = OrderedDict()
-        feats['conv0'] = nn.Conv2d(3, cs, 7, stride=2, padding=3, bias=False)
-        feats['norm0'] = nn.BatchNorm2d(cs)
-        feats['relu0'] = nn.ReLU(inplace=True)
-        feats['pool0'] = nn.MaxPool2d(3, stride=2, padding=1)
-        self.features = nn.Sequential(feats)
+        if sp.kind == 'mobilenet':
+            self.features = _holder_mobilenet(sp)
+        else:
+            feats['conv0'] = nn.Conv2d(3, cs, 7, stride=2, padding=3, bias=False)
+            feats['norm0'] = nn.BatchNorm2d(cs)
+            feats['relu0'] = nn.ReLU(inplace=True)
+            feats['pool0'] = nn.MaxPool2d(3, stride=2, padding=1)
+            self.features = nn.Sequential(feats)
         for blk in sp.blocks:
             block = nn.Sequential()
             for i, l in enumerate(blk.layers):
@@ -103,7 +126,8 @@ class DenseASPP(nn.Module):
             if blk.pool_after:
                 tr.add_module('pool', nn.AvgPool2d(2, stride=2))
             self.features.add_module('transition%d' % blk.index, tr)
-        self.features.add_module('norm5', nn.BatchNorm2d(sp.c_feat))
+        if sp.kind != 'mobilenet':
+            self.features.add_module('norm5', nn.BatchNorm2d(sp.c_feat))
         for a in sp.aspp:
             setattr(self, a.prefix, _holder_aspp(a.cin, a.d0, a.d1, a.rate, a.bn_start))
         self.classification = nn.Sequential(
@@ -177,13 +201,16 @@ class DenseASPP(nn.Module):
             nk = k
             if prefix == '' and nk.startswith('module.'):
                 nk = nk[len('module.'):]
-            nk = _LEGACY.sub(lambda m: '.%s%s.' % (m.group(1), m.group(2)), nk)
+            if '.conv.' not in nk or 'denselayer' in nk or nk.startswith('ASPP_'):
+                # legacy dotted child names of dense layers / ASPP blocks ("norm.1" -> "norm1"); the MobileNet
+                # trunk's "features.features.<i>.conv.<j>" names are Sequential indices and stay as they are
+                nk = _LEGACY.sub(lambda m: '.%s%s.' % (m.group(1), m.group(2)), nk)
             if nk != k:
                 state_dict[nk] = state_dict.pop(k)
 
     def _flatten(self):
         """(Re)build the flat arenas on the device the parameters currently live on."""
-        dev = self.features.conv0.weight.device
+        dev = next(self.parameters()).device
         for p in self.parameters():
             if p.dtype != torch.float32:
                 raise TypeError('DenseASPP keeps fp32 master parameters; the kernels compute in bf16 with fp32 accumulation')
@@ -194,6 +221,7 @@ class DenseASPP(nn.Module):
             v.copy_(named[name].data)
             named[name].data = v
         self._flat = flat
+        object.__setattr__(self, '_first_param', named[self._param_names[0]])    # plain attribute, not a registered Parameter
         self._gflat = torch.zeros_like(flat)
         self._alloc_shadows()
         self._buffers_flat = {n: b for n, b in self.named_buffers()}
@@ -207,7 +235,7 @@ class DenseASPP(nn.Module):
         dev = self._flat.device
         self._w16 = torch.zeros(self.arena.size, dtype=dt, device=dev)
         self._wt16 = torch.zeros(max(self.arena.tsize, 8), dtype=dt, device=dev)
-        self._w0_16 = torch.zeros(self.spec.c_stem * S.STEM_KPAD, dtype=dt, device=dev)
+        self._w0_16 = torch.zeros(self.spec.c_stem * S.STEM_KPAD, dtype=dt, device=dev)   # padded 7x7 stem rows (DenseNet trunk)
 
     def _apply(self, fn, *a, **k):
         super()._apply(fn, *a, **k)
@@ -215,9 +243,10 @@ class DenseASPP(nn.Module):
         return self
 
     def _check_arena(self):
-        p = self.features.conv0.weight
+        first = self._param_names[0]
+        p = dict(self.named_parameters())[first] if self._flat is None else self._first_param
         if (self._flat is None or p.device != self._flat.device
-                or p.data_ptr() != self._flat.data_ptr() + 4 * self.arena.by_name['features.conv0.weight'].off
+                or p.data_ptr() != self._flat.data_ptr() + 4 * self.arena.by_name[first].off
                 or self.classification[1].bias.data_ptr() != self._flat.data_ptr() + 4 * self.arena.by_name['classification.1.bias'].off):
             self._flatten()
 
@@ -323,8 +352,8 @@ class DenseASPP(nn.Module):
             reducer.run_backward()
         else:
             eng._bwd.run()
-        if self.features.conv0.weight.grad is None or \
-                self.features.conv0.weight.grad.data_ptr() != self._gflat.data_ptr() + 4 * self.arena.by_name['features.conv0.weight'].off:
+        g0 = self._first_param.grad
+        if g0 is None or g0.data_ptr() != self._gflat.data_ptr() + 4 * self.arena.by_name[self._param_names[0]].off:
             self.bind_grads()
         return eng.loss
 

@@ -94,17 +94,24 @@ class Engine:
         self.M0, self.M1, self.M2 = B * self.H0 * self.W0, B * self.H1 * self.W1, B * self.H2 * self.W2
 
         # ---- activations
+        self.mobilenet = sp.kind == 'mobilenet'
+        if self.mobilenet and training:
+            raise NotImplementedError('MobileNetDenseASPP on the MI355X path is inference only: call eval() first '
+                                      '(the depthwise / inverted-residual backward is not built)')
         self.x_in = zeros(B * 3 * height * width)
-        self.col = zeros(self.M0 * S.STEM_KPAD, bf16)
-        self.c0out = zeros(self.M0 * sp.c_stem, bf16)
         self.slabs = []
-        for blk in sp.blocks:
-            M, H, W = (self.M1, self.H1, self.W1) if blk.index == 1 else (self.M2, self.H2, self.W2)
-            self.slabs.append(Slab(self, M, blk.C, H, W, training))
         self.aslab = Slab(self, self.M2, sp.C_aspp, self.H2, self.W2, training)
-        self.t1tmp = zeros(self.M1 * sp.blocks[0].cout, bf16)
-        self.t4out = zeros(self.M2 * sp.c_feat, bf16)
         self.logits = zeros(self.M2 * S.CLS_PAD)
+        if self.mobilenet:
+            self._alloc_mobilenet(zeros, bf16)
+        else:
+            self.col = zeros(self.M0 * S.STEM_KPAD, bf16)
+            self.c0out = zeros(self.M0 * sp.c_stem, bf16)
+            for blk in sp.blocks:
+                M, H, W = (self.M1, self.H1, self.W1) if blk.index == 1 else (self.M2, self.H2, self.W2)
+                self.slabs.append(Slab(self, M, blk.C, H, W, training))
+            self.t1tmp = zeros(self.M1 * sp.blocks[0].cout, bf16)
+            self.t4out = zeros(self.M2 * sp.c_feat, bf16)
         # bottleneck tensors: kept per layer when training (needed by backward), shared otherwise
         self.y1 = {}
         shared = {}
@@ -138,9 +145,16 @@ class Engine:
         def accbuf(name, C):
             self.acc[name] = zeros(self.R * 2 * C)
 
-        bn_tables('features.norm0', sp.c_stem)
-        accbuf('features.norm0', sp.c_stem)
-        accbuf('pool0', sp.c_stem)
+        if self.mobilenet:
+            bn_tables(sp.stem_prefix + '.1', sp.c_stem)
+            for b in sp.ir:
+                bn_tables(b.prefix + '.conv.1', b.hid)
+                bn_tables(b.prefix + '.conv.4', b.hid)
+                bn_tables(b.prefix + '.conv.7', b.cout)
+        else:
+            bn_tables('features.norm0', sp.c_stem)
+            accbuf('features.norm0', sp.c_stem)
+            accbuf('pool0', sp.c_stem)
         for blk in sp.blocks:
             for l in blk.layers:
                 bn_tables(l.prefix + '.norm1', l.cin)
@@ -154,7 +168,8 @@ class Engine:
             accbuf(blk.trans_prefix + '.out', blk.cout)
             if training:
                 accbuf(blk.trans_prefix + '.s', blk.C)
-        bn_tables('features.norm5', sp.c_feat)
+        if not self.mobilenet:
+            bn_tables('features.norm5', sp.c_feat)
         accbuf('feat', sp.c_feat)
         if training:
             accbuf('features.norm5.s', sp.c_feat)
@@ -203,6 +218,28 @@ class Engine:
         self._up_fwd = None
         self._up_bwd = None
         self._argmax = None
+
+    def _alloc_mobilenet(self, zeros, dt):
+        """Trunk buffers of the MobileNetV2 variant: two block in/out tensors (ping-pong) and the two
+        expanded tensors of an inverted-residual block, each sized for the largest block."""
+        sp = self.spec
+        h, w = self.H0, self.W0
+        self.stem_out = zeros(self.M0 * sp.c_stem, dt)
+        n_io = n_e1 = n_e2 = 8
+        self.ir_geom = []
+        for b in sp.ir:
+            ho, wo = (h - 1) // b.stride + 1, (w - 1) // b.stride + 1
+            self.ir_geom.append((h, w, ho, wo))
+            n_e1 = max(n_e1, self.B * h * w * b.hid)
+            n_e2 = max(n_e2, self.B * ho * wo * b.hid)
+            n_io = max(n_io, self.B * ho * wo * b.cout)
+            h, w = ho, wo
+        if (h, w) != (self.H2, self.W2):
+            raise ValueError('MobileNet trunk output %dx%d is not 1/8 of the input' % (h, w))
+        self.ir_io = [zeros(n_io, dt), zeros(n_io, dt)]
+        self.ir_e1 = zeros(n_e1, dt)
+        self.ir_e2 = zeros(n_e2, dt)
+        self.ir_p = zeros(n_io, dt)
 
     # ------------------------------------------------------------------ helpers
     def P(self, name):
@@ -266,6 +303,11 @@ class Engine:
             d = dict(conv)
             d.update(kw)
             ops.op('conv', **d)
+
+        if self.mobilenet:
+            self._build_trunk_mobilenet(ops, C)
+            self._build_head(ops, C)
+            return ops
 
         # ---- stem: im2col + GEMM, norm0 statistics, BN-ReLU-maxpool into slab 1
         cs = sp.c_stem
@@ -335,6 +377,53 @@ class Engine:
                    mean=_r(A.mean, sp.off_feat), var=_r(A.var, sp.off_feat), rstd=_r(A.rstd, sp.off_feat),
                    gamma=None, beta=None, running_mean=None, running_var=None, num_batches_tracked=None,
                    momentum=0.0, eps=1e-5, use_running=0, scale=None, shift=None)
+        self._build_head(ops, C)
+        return ops
+
+    def _build_trunk_mobilenet(self, ops, C):
+        """MobileNetV2 trunk (eval mode): every BatchNorm is applied by its consumer -- in the prologue of the
+        next convolution, or by the bn_act that closes a block (which also adds the skip connection)."""
+        sp, B = self.spec, self.B
+        n0 = sp.stem_prefix + '.1'
+        ops.op('stem3', n_img=B, H=self.H, W=self.W, x=_r(self.x_in), w=self.W16(sp.stem_prefix + '.0.weight'),
+               cout=sp.c_stem, y=_r(self.stem_out), ldy=sp.c_stem)
+        self._bn_finalize(ops, n0, sp.c_stem, count=self.M0)
+        cur, cur_c = self.stem_out, sp.c_stem
+        cur_pro = dict(in_scale=self.bnt(n0, 'scale', sp.c_stem), in_shift=self.bnt(n0, 'shift', sp.c_stem), in_relu=2)
+        A = self.aslab
+        for i, b in enumerate(sp.ir):
+            h, w, ho, wo = self.ir_geom[i]
+            n1, n2, n3 = b.prefix + '.conv.1', b.prefix + '.conv.4', b.prefix + '.conv.7'
+            C(n_img=B, H=h, W=w, cin=b.cin, cout=b.hid, taps=1, dil=1, x=_r(cur), ldx=cur_c,
+              w=self.W16(b.prefix + '.conv.0.weight'), y=_r(self.ir_e1), ldy=b.hid, **cur_pro)
+            self._bn_finalize(ops, n1, b.hid, count=B * h * w)
+            ops.op('dwconv', n_img=B, H=h, W=w, C=b.hid, stride=b.stride, dil=b.dil, x=_r(self.ir_e1), ldx=b.hid,
+                   in_scale=self.bnt(n1, 'scale', b.hid), in_shift=self.bnt(n1, 'shift', b.hid), in_relu=2,
+                   w=self.W16(b.prefix + '.conv.3.weight'), y=_r(self.ir_e2), ldy=b.hid)
+            self._bn_finalize(ops, n2, b.hid, count=B * ho * wo)
+            C(n_img=B, H=ho, W=wo, cin=b.hid, cout=b.cout, taps=1, dil=1, x=_r(self.ir_e2), ldx=b.hid,
+              w=self.W16(b.prefix + '.conv.6.weight'), in_scale=self.bnt(n2, 'scale', b.hid),
+              in_shift=self.bnt(n2, 'shift', b.hid), in_relu=2, y=_r(self.ir_p), ldy=b.cout)
+            self._bn_finalize(ops, n3, b.cout, count=B * ho * wo)
+            last = i == len(sp.ir) - 1
+            if last:      # ReLU(trunk) goes straight into the ASPP slab (the in-place ReLU heading ASPP_3)
+                dst, ldd = _r(A.x, sp.off_feat), A.C
+            else:
+                nxt = self.ir_io[i % 2]
+                dst, ldd = _r(nxt), b.cout
+            res = (_r(cur), cur_c) if b.residual else (None, 0)
+            if b.residual and cur_pro:
+                raise AssertionError('residual block fed by an unnormalised tensor')
+            ops.op('bn_act', M=B * ho * wo, C=b.cout, x=_r(self.ir_p), ldx=b.cout, scale=self.bnt(n3, 'scale', b.cout),
+                   shift=self.bnt(n3, 'shift', b.cout), relu=1 if last else 0, y=dst, ldy=ldd, stat_acc=None,
+                   res=res[0], ldres=res[1])
+            if not last:
+                cur, cur_c, cur_pro = nxt, b.cout, {}
+
+    def _build_head(self, ops, C):
+        """ASPP stack + classifier on the ASPP slab whose feature channels hold ReLU(trunk output)."""
+        sp, tr, B = self.spec, self.training, self.B
+        A = self.aslab
         pending = None
         H, W, M = self.H2, self.W2, self.M2
         for i, a in enumerate(sp.aspp):
@@ -365,7 +454,6 @@ class Engine:
           w=self.W16('classification.1.weight'), bias=self.P('classification.1.bias'),
           in_mask=_r(self.dropmask, 5 * sp.d1) if tr else None, in_mask_ld=self.drop_ld if tr else 0,
           y=_r(self.logits), ldy=S.CLS_PAD, y_f32=1)
-        return ops
 
     # ------------------------------------------------------------------ loss (fused upsample + CE)
     def build_loss(self, ignore_index=255, grad_scale=1.0):

@@ -43,6 +43,8 @@ def _prologue(x, f, n_img, hw, cin):
         a = a * _vec(f['in_scale'], cin) + _vec(f['in_shift'], cin)
     if f['in_relu']:
         a = a.clamp_min(0)
+    if f['in_relu'] == 2:
+        a = a.clamp_max(6)
     if f['in_mask'] is not None:
         mk = _view(f['in_mask'], n_img, cin, f['in_mask_ld'])
         a = (a.view(n_img, hw, cin) * mk[:, None, :]).reshape(-1, cin)
@@ -194,8 +196,12 @@ def op_bn_act(f):
     v = x
     if f['scale'] is not None:
         v = v * _vec(f['scale'], C) + _vec(f['shift'], C)
+    if f.get('res') is not None:
+        v = v + _view(f['res'], M, C, f['ldres']).to(torch.float32)
     if f['relu']:
         v = v.clamp_min(0)
+    if f['relu'] == 2:
+        v = v.clamp_max(6)
     _view(f['y'], M, C, f['ldy']).copy_(v.to(bf16))
     if f['stat_acc'] is not None:
         s = _rbf(v)
@@ -270,6 +276,34 @@ def op_im2col(f):
     out = _view(f['col'], n * L, f['ldcol'], f['ldcol'])
     out.zero_()
     out[:, :147] = cols.to(bf16)
+
+
+def op_stem3(f):
+    n, H, W, cout = f['n_img'], f['H'], f['W'], f['cout']
+    x = torch.as_strided(f['x'].t, (n, 3, H, W), (3 * H * W, H * W, W, 1), f['x'].off)
+    w = _view(f['w'], cout, 27, 27).to(torch.float32).view(cout, 3, 3, 3).permute(0, 3, 1, 2)    # stored (ky, kx, ci)
+    y = F.conv2d(_rbf(x), w, stride=2, padding=1)
+    y = y.permute(0, 2, 3, 1).reshape(-1, cout)
+    _view(f['y'], y.shape[0], cout, f['ldy']).copy_(y.to(bf16))
+
+
+def op_dwconv(f):
+    n, H, W, C, st, dil = f['n_img'], f['H'], f['W'], f['C'], f['stride'], f['dil']
+    x = _view(f['x'], n * H * W, C, f['ldx']).to(torch.float32)
+    a = x
+    if f['in_scale'] is not None:
+        a = a * _vec(f['in_scale'], C) + _vec(f['in_shift'], C)
+    if f['in_relu']:
+        a = a.clamp_min(0)
+    if f['in_relu'] == 2:
+        a = a.clamp_max(6)
+    if f['in_scale'] is not None or f['in_relu']:
+        a = _rbf(a)
+    a4 = a.view(n, H, W, C).permute(0, 3, 1, 2)
+    w = _view(f['w'], C, 9, 9).to(torch.float32).view(C, 1, 3, 3)
+    y = F.conv2d(a4, w, stride=st, padding=dil, dilation=dil, groups=C)
+    y = y.permute(0, 2, 3, 1).reshape(-1, C)
+    _view(f['y'], y.shape[0], C, f['ldy']).copy_(y.to(bf16))
 
 
 def op_maxpool_fwd(f):
@@ -398,6 +432,7 @@ OPS = {
     'avgpool_fwd': op_avgpool_fwd, 'avgpool_bwd': op_avgpool_bwd, 'im2col': op_im2col,
     'maxpool_fwd': op_maxpool_fwd, 'maxpool_bwd': op_maxpool_bwd, 'upce': op_upce, 'ce_finalize': op_ce_finalize,
     'up_fwd': op_up_fwd, 'up_bwd': op_up_bwd, 'up_argmax': op_up_argmax, 'memset': op_memset, 'copy2d': op_copy2d,
+    'stem3': op_stem3, 'dwconv': op_dwconv,
 }
 
 
@@ -436,11 +471,12 @@ class ModelBackend:
     def refresh_weights(self, model, cast=True):
         ar = model.arena
         model._w16.copy_(model._flat.to(bf16))
-        e0 = ar.by_name['features.conv0.weight']
-        w0 = model._flat[e0.off:e0.off + e0.rows * 147].view(e0.rows, 147)
-        p = model._w0_16.view(e0.rows, -1)
-        p.zero_()
-        p[:, :147] = w0.to(bf16)
+        if 'features.conv0.weight' in ar.by_name:
+            e0 = ar.by_name['features.conv0.weight']
+            w0 = model._flat[e0.off:e0.off + e0.rows * 147].view(e0.rows, 147)
+            p = model._w0_16.view(e0.rows, -1)
+            p.zero_()
+            p[:, :147] = w0.to(bf16)
         for e in ar.entries:
             if e.kind != 'conv':
                 continue

@@ -1,0 +1,96 @@
+"""CPU tests (no GPU) of the MobileNetDenseASPP variant: module surface and the recorded eval-mode program
+run through the CPU kernel model against the oracle (oracle/mobilenet_dense_aspp_ref.py)."""
+import pytest
+import torch
+
+import denseASPP
+import kernel_model
+from cfgs import MobileNetDenseASPP
+from e2e_common import make_batch
+from oracle import mobilenet_dense_aspp_ref as mref
+
+CFG = MobileNetDenseASPP.Model_CFG
+
+
+def make_mobilenet_pair(seed=0):
+    torch.manual_seed(seed)
+    ref = mref.MobileNetDenseASPPRef(CFG)
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.3, 0.3)
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    mod = denseASPP.DenseASPP(CFG)
+    mod.load_state_dict(ref.state_dict())
+    return ref, mod
+
+
+@pytest.fixture
+def fp32_model():
+    kernel_model.set_act_dtype(torch.float32)
+    yield
+    kernel_model.set_act_dtype(torch.bfloat16)
+
+
+def test_state_dict_and_macs_match_oracle():
+    ref, mod = make_mobilenet_pair()
+    sr, sm = ref.state_dict(), mod.state_dict()
+    assert list(sr.keys()) == list(sm.keys())
+    for k in sr:
+        assert sr[k].shape == sm[k].shape and torch.equal(sr[k], sm[k]), k
+    assert mod.spec.kind == 'mobilenet'
+    assert mod.conv_macs(1024, 2048) == mref.conv_macs(CFG, 1024, 2048)
+    # both constructor forms of the reference call sites (graph_seg_test.py:129)
+    assert denseASPP.DenseASPP(object(), model_cfg=CFG).spec.kind == 'mobilenet'
+
+
+def test_eval_forward_fp32(fp32_model):
+    ref, mod = make_mobilenet_pair()
+    mod.set_backend(kernel_model.ModelBackend())
+    x, _ = make_batch(2, 64, 96)
+    ref.eval(); mod.eval()
+    with torch.no_grad():
+        yr, ym = ref(x), mod(x)
+    assert ym.shape == yr.shape == (2, 19, 64, 96)
+    assert float((yr - ym).abs().max() / yr.abs().max()) < 1e-4
+    assert float((mod.predict(x) == yr.argmax(1)).float().mean()) > 0.999
+
+
+def bf16_yardstick(ref, x):
+    """Error of the fp32 oracle against itself when only its conv weights and the input are rounded to bf16.
+
+    A randomly initialised 52-convolution MobileNetV2 trunk amplifies perturbations by 1.2-1.5x per block
+    (no dense connectivity to carry early features forward), so the 2e-2 budget that holds for the DenseNet
+    variant is not meaningful here; the product's bf16 error is bounded by a multiple of this inherent one."""
+    import copy
+    r2 = copy.deepcopy(ref)
+    for p in r2.parameters():
+        if p.dim() == 4:
+            p.data = p.data.bfloat16().float()
+    with torch.no_grad():
+        yr, y2 = ref.forward_lowres(x), r2.forward_lowres(x.bfloat16().float())
+    return float((yr - y2).pow(2).mean().sqrt() / yr.pow(2).mean().sqrt())
+
+
+def rms_rel(yr, y):
+    return float((yr - y).pow(2).mean().sqrt() / yr.pow(2).mean().sqrt())
+
+
+def test_eval_forward_bf16_model():
+    ref, mod = make_mobilenet_pair()
+    mod.set_backend(kernel_model.ModelBackend())
+    x, _ = make_batch(1, 64, 128)
+    ref.eval(); mod.eval()
+    with torch.no_grad():
+        yr, ym = ref.forward_lowres(x), mod.forward_lowres(x)
+    yard = bf16_yardstick(ref, x)
+    assert rms_rel(yr, ym) < 2.0 * yard, (rms_rel(yr, ym), yard)
+
+
+def test_training_mode_is_refused():
+    _, mod = make_mobilenet_pair()
+    mod.set_backend(kernel_model.ModelBackend())
+    mod.train()
+    with pytest.raises(NotImplementedError):
+        mod.train_step(*make_batch(1, 32, 32))
