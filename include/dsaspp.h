@@ -12,6 +12,11 @@
  *
  * Layouts: activations are NHWC with an explicit pixel stride ("ld", in elements) so a
  * layer can read or write a channel slice of a wider feature slab; bf16 unless stated.
+ * Descriptors with a `dtype` field also have an fp32 form (dtype = 1): activations AND the
+ * weights they are multiplied with are then fp32 (weights straight from the fp32 master
+ * arena, same [cout][taps][cin] layout), arithmetic is fp32 throughout.  That form covers the
+ * eval-mode forward pass only (no statistics, no gradient epilogues) and exists so that the
+ * network can be checked against an fp32 reference to 1e-4.
  * Convolution weights are bf16 [cout][taps][cin] (K contiguous).  Channel counts, channel
  * offsets and strides must be multiples of 8 (16-byte chunks).
  */
@@ -91,6 +96,7 @@ typedef struct dsaspp_conv_desc {
     const void* x1; const void* w1; const float* es1; const float* eh1; float* sa1; int32_t sl1;
     const void* x2; const void* w2; const float* es2; const float* eh2; float* sa2; int32_t sl2;
     const void* x3; const void* w3; const float* es3; const float* eh3; float* sa3; int32_t sl3;
+    int32_t dtype;            /* storage type of the activation tensors: 0 = bf16 (default), 1 = fp32 (eval-mode forward only) */
 } dsaspp_conv_desc;
 
 int dsaspp_conv_fwd(const dsaspp_conv_desc* d, dsaspp_stream_t stream);
@@ -197,6 +203,7 @@ typedef struct dsaspp_bnact_desc {
     void* y; int32_t ldy;
     float* stat_acc;          /* [R][2*C] or NULL */
     const void* res; int32_t ldres;   /* bf16 [M][ldres] added after the affine map, or NULL */
+    int32_t dtype;            /* storage type of the activation tensors: 0 = bf16 (default), 1 = fp32 (eval-mode forward only) */
 } dsaspp_bnact_desc;
 int dsaspp_bn_act(const dsaspp_bnact_desc* d, dsaspp_stream_t stream);
 
@@ -241,6 +248,7 @@ typedef struct dsaspp_pool_desc {
     const void* x; int32_t ldx;
     void* y; int32_t ldy;     /* output geometry H/2 x W/2 */
     float* stat_acc;
+    int32_t dtype;            /* storage type of the activation tensors: 0 = bf16 (default), 1 = fp32 (eval-mode forward only) */
 } dsaspp_pool_desc;
 int dsaspp_avgpool2_fwd(const dsaspp_pool_desc* d, dsaspp_stream_t stream);
 /* dx[n][h][w][c] = dy[n][h/2][w/2][c] / 4 ; here x is the gradient OUTPUT (full size), y the INPUT */
@@ -253,6 +261,7 @@ typedef struct dsaspp_im2col_desc {
     int32_t n_img, H, W;      /* input image size; output Ho = H/2, Wo = W/2 */
     const float* x;           /* NCHW fp32, 3 channels */
     void* col; int32_t ldcol; /* >= 152 and multiple of 8; columns >= 147 zero filled */
+    int32_t dtype;            /* storage type of the activation tensors: 0 = bf16 (default), 1 = fp32 (eval-mode forward only) */
 } dsaspp_im2col_desc;
 int dsaspp_stem_im2col(const dsaspp_im2col_desc* d, dsaspp_stream_t stream);
 
@@ -269,6 +278,7 @@ typedef struct dsaspp_maxpool_desc {
     int32_t dr_f32;
     const float* mean; const float* rstd;
     float* s_acc;
+    int32_t dtype;            /* storage type of the activation tensors: 0 = bf16 (default), 1 = fp32 (eval-mode forward only) */
 } dsaspp_maxpool_desc;
 int dsaspp_maxpool3s2_fwd(const dsaspp_maxpool_desc* d, dsaspp_stream_t stream);
 int dsaspp_maxpool3s2_bwd(const dsaspp_maxpool_desc* d, dsaspp_stream_t stream);
@@ -288,6 +298,7 @@ typedef struct dsaspp_stem3_desc {
     const void* w;
     int32_t cout;
     void* y; int32_t ldy;
+    int32_t dtype;            /* storage type of the activation tensors: 0 = bf16 (default), 1 = fp32 (eval-mode forward only) */
 } dsaspp_stem3_desc;
 int dsaspp_stem3x3s2(const dsaspp_stem3_desc* d, dsaspp_stream_t stream);
 
@@ -303,6 +314,7 @@ typedef struct dsaspp_dw_desc {
     const float* in_scale; const float* in_shift; int32_t in_relu;
     const void* w;            /* bf16 [C][9] */
     void* y; int32_t ldy;
+    int32_t dtype;            /* storage type of the activation tensors: 0 = bf16 (default), 1 = fp32 (eval-mode forward only) */
 } dsaspp_dw_desc;
 int dsaspp_dwconv3x3(const dsaspp_dw_desc* d, dsaspp_stream_t stream);
 

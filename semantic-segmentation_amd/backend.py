@@ -52,9 +52,13 @@ class HipBackend:
     """Runs descriptor lists through libdsaspp.so.  There is no other compute backend in the package."""
     stat_replicas = _lib.STAT_REPLICAS
     act_dtype = torch.bfloat16
+    forward_only_fp32 = True      # the fp32 kernels implement the eval-mode forward pass only
 
-    def __init__(self):
+    def __init__(self, act_dtype=torch.bfloat16):
+        if act_dtype not in (torch.bfloat16, torch.float32):
+            raise TypeError('activation storage must be torch.bfloat16 or torch.float32')
         self.lib = _lib.load()
+        self.act_dtype = act_dtype
 
     def compile(self, oplist):
         h = self.lib.dsaspp_program_create()
@@ -82,6 +86,14 @@ class HipBackend:
         lib = self.lib
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         ar = model.arena
+        if self.act_dtype == torch.float32:
+            # fp32 form: the kernels read the fp32 master arena itself (model._w16 aliases it); only the
+            # row-padded copy of the 7x7 stem weight has to be refreshed
+            e0 = ar.by_name.get('features.conv0.weight')
+            if e0 is not None:
+                _lib.check(lib.dsaspp_copy2d_f32(model._flat.data_ptr() + 4 * e0.off, S.STEM_K, model._w0_16.data_ptr(),
+                                                 S.STEM_KPAD, e0.rows, S.STEM_K, S.STEM_KPAD, 0, stream))
+            return
         if cast:
             _lib.check(lib.dsaspp_cast_bf16(model._flat.data_ptr(), model._w16.data_ptr(), ar.size, stream))
         e0 = ar.by_name.get('features.conv0.weight')

@@ -17,6 +17,16 @@ int dsaspp_dgrad_group_launch(const dsaspp_conv_desc& d, hipStream_t s);
 // halo-patch 3x3 convolution with few output channels (conv3x3_halo.hip): same return convention
 int dsaspp_conv3x3_halo_launch(const dsaspp_conv_desc& d, hipStream_t s);
 
+// fp32 forms (descriptor dtype == 1) of the eval-mode forward kernels (fp32_path.hip); called by the public entry
+// points after their argument checks
+int dsaspp_f32_conv(const dsaspp_conv_desc& d, hipStream_t s);
+int dsaspp_f32_bn_act(const dsaspp_bnact_desc& d, hipStream_t s);
+int dsaspp_f32_avgpool(const dsaspp_pool_desc& d, hipStream_t s);
+int dsaspp_f32_im2col(const dsaspp_im2col_desc& d, hipStream_t s);
+int dsaspp_f32_maxpool(const dsaspp_maxpool_desc& d, hipStream_t s);
+int dsaspp_f32_stem3(const dsaspp_stem3_desc& d, hipStream_t s);
+int dsaspp_f32_dwconv(const dsaspp_dw_desc& d, hipStream_t s);
+
 #define DS_REQUIRE(cond, ...)                                  \
     do {                                                       \
         if (!(cond)) return dsaspp_set_error(__VA_ARGS__);     \

@@ -588,6 +588,8 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
     if (d.in_mask) DS_REQUIRE(d.in_mask_ld % 4 == 0, "conv_fwd: in_mask_ld must be a multiple of 4");
     if (d.out_mask) DS_REQUIRE(d.out_mask_ld % 4 == 0, "conv_fwd: out_mask_ld must be a multiple of 4");
 
+    DS_REQUIRE(d.dtype == 0 || d.dtype == 1, "conv_fwd: dtype must be 0 (bf16) or 1 (fp32)");
+    if (d.dtype == 1) return dsaspp_f32_conv(d, s);
     if (d.n_src > 1) {
         DS_REQUIRE(d.n_src <= 4, "conv_fwd: at most 4 sources (got %d)", d.n_src);
         DS_REQUIRE(d.g && d.epi_relu && d.taps == 1 && d.ref && d.e_scale && d.e_shift && d.e_mean && d.e_rstd && !d.in_scale && !d.in_mask && !d.in_relu && !d.bias && !d.out_mask,

@@ -483,6 +483,7 @@ extern "C" int dsaspp_bn_act(const dsaspp_bnact_desc* d, dsaspp_stream_t stream)
     DS_REQUIRE(d->x && d->y, "bn_act: null tensor");
     DS_REQUIRE(d->relu >= 0 && d->relu <= 2, "bn_act: relu must be 0, 1 or 2");
     if (d->res) DS_REQUIRE(d->ldres % 8 == 0 && d->ldres >= d->C && ((uintptr_t)d->res & 15) == 0, "bn_act: bad residual stride/alignment");
+    if (d->dtype == 1) return dsaspp_f32_bn_act(*d, (hipStream_t)stream);
     ROW_DISPATCH(bn_act_kernel, d->C, d->M, *d, (hipStream_t)stream);
     DS_LAUNCH_CHECK("bn_act");
     return 0;
@@ -511,6 +512,7 @@ extern "C" int dsaspp_bn_bwd_apply(const dsaspp_bnapply_desc* d, dsaspp_stream_t
 extern "C" int dsaspp_avgpool2_fwd(const dsaspp_pool_desc* d, dsaspp_stream_t stream) {
     DS_REQUIRE(d && d->n_img > 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0, "avgpool2_fwd: H and W must be even");
     DS_REQUIRE(d->C > 0 && d->C % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->x && d->y, "avgpool2_fwd: bad descriptor");
+    if (d->dtype == 1) return dsaspp_f32_avgpool(*d, (hipStream_t)stream);
     const int64_t Mo = (int64_t)d->n_img * (d->H / 2) * (d->W / 2);
     ROW_DISPATCH(avgpool_fwd_kernel, d->C, Mo, *d, (hipStream_t)stream);
     DS_LAUNCH_CHECK("avgpool2_fwd");
@@ -529,6 +531,7 @@ extern "C" int dsaspp_avgpool2_bwd(const dsaspp_pool_desc* d, dsaspp_stream_t st
 extern "C" int dsaspp_stem_im2col(const dsaspp_im2col_desc* d, dsaspp_stream_t stream) {
     DS_REQUIRE(d && d->n_img > 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0, "stem_im2col: H and W must be even");
     DS_REQUIRE(d->x && d->col && d->ldcol >= 152 && d->ldcol % 8 == 0, "stem_im2col: ldcol must be >= 152 and a multiple of 8");
+    if (d->dtype == 1) return dsaspp_f32_im2col(*d, (hipStream_t)stream);
     const int64_t total = (int64_t)d->n_img * (d->H / 2) * (d->W / 2) * (d->ldcol / 8);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
@@ -540,6 +543,7 @@ extern "C" int dsaspp_stem_im2col(const dsaspp_im2col_desc* d, dsaspp_stream_t s
 extern "C" int dsaspp_maxpool3s2_fwd(const dsaspp_maxpool_desc* d, dsaspp_stream_t stream) {
     DS_REQUIRE(d && d->n_img > 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0, "maxpool3s2_fwd: H and W must be even");
     DS_REQUIRE(d->C > 0 && d->C % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->x && d->y && d->scale && d->shift, "maxpool3s2_fwd: bad descriptor");
+    if (d->dtype == 1) return dsaspp_f32_maxpool(*d, (hipStream_t)stream);
     const int64_t Mo = (int64_t)d->n_img * (d->H / 2) * (d->W / 2);
     ROW_DISPATCH(maxpool_fwd_kernel, d->C, Mo, *d, (hipStream_t)stream);
     DS_LAUNCH_CHECK("maxpool3s2_fwd");

@@ -140,6 +140,7 @@ extern "C" int dsaspp_stem3x3s2(const dsaspp_stem3_desc* dp, dsaspp_stream_t str
     DS_REQUIRE(d.cout > 0 && d.cout % 8 == 0 && d.cout <= 64, "stem3x3s2: cout must be a multiple of 8, at most 64 (got %d)", d.cout);
     DS_REQUIRE(d.x && d.w && d.y, "stem3x3s2: null tensor");
     DS_REQUIRE(d.ldy % 8 == 0 && d.ldy >= d.cout && ((uintptr_t)d.y & 15) == 0, "stem3x3s2: output stride/alignment");
+    if (d.dtype == 1) return dsaspp_f32_stem3(d, (hipStream_t)stream);
     const int Ho = d.H / 2, Wo = d.W / 2, cg = d.cout / 8;
     const int64_t total = (int64_t)d.n_img * Ho * Wo * cg;
     DS_REQUIRE(total < (1ll << 31) - (1 << 23), "stem3x3s2: too many output chunks");
@@ -162,6 +163,7 @@ extern "C" int dsaspp_dwconv3x3(const dsaspp_dw_desc* dp, dsaspp_stream_t stream
     DS_REQUIRE((((uintptr_t)d.x | (uintptr_t)d.y) & 15) == 0, "dwconv3x3: tensors must be 16-byte aligned");
     DS_REQUIRE((d.in_scale == nullptr) == (d.in_shift == nullptr), "dwconv3x3: in_scale/in_shift must come together");
     DS_REQUIRE(d.in_relu >= 0 && d.in_relu <= 2, "dwconv3x3: in_relu must be 0, 1 or 2");
+    if (d.dtype == 1) return dsaspp_f32_dwconv(d, (hipStream_t)stream);
     const int Ho = (d.H - 1) / d.stride + 1, Wo = (d.W - 1) / d.stride + 1, cg = d.C / 8;
     const int64_t total = (int64_t)d.n_img * Ho * Wo * cg;
     DS_REQUIRE(total < (1ll << 31) - (1 << 22), "dwconv3x3: too many output chunks");

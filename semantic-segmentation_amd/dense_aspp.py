@@ -161,6 +161,7 @@ class DenseASPP(nn.Module):
         for name, m in self.named_modules():
             if isinstance(m, nn.BatchNorm2d):
                 self.bn_modules[name] = m
+        self.compute_dtype = torch.bfloat16      # activation storage / MFMA input type; see set_compute_dtype
         self.grad_slab_dtype = torch.bfloat16    # dtype of the feature-slab gradient (torch.float32: exact accumulation, 2x traffic)
         self.bn_grad_dtype = torch.bfloat16      # dtype of the BatchNorm-backward inputs (torch.float32: unrounded)
         self.dgrad_group = 4                     # dense layers whose slab data gradients share one pass (1..4)
@@ -231,9 +232,12 @@ class DenseASPP(nn.Module):
             named[name].grad = None
 
     def _alloc_shadows(self):
-        dt = self._backend.act_dtype if self._backend is not None else torch.bfloat16
+        dt = self._backend.act_dtype if self._backend is not None else self.compute_dtype
         dev = self._flat.device
-        self._w16 = torch.zeros(self.arena.size, dtype=dt, device=dev)
+        if dt == torch.float32 and getattr(self._backend, 'forward_only_fp32', False):
+            self._w16 = self._flat      # fp32 kernels read the master weights themselves
+        else:
+            self._w16 = torch.zeros(self.arena.size, dtype=dt, device=dev)
         self._wt16 = torch.zeros(max(self.arena.tsize, 8), dtype=dt, device=dev)
         self._w0_16 = torch.zeros(self.spec.c_stem * S.STEM_KPAD, dtype=dt, device=dev)   # padded 7x7 stem rows (DenseNet trunk)
 
@@ -268,8 +272,22 @@ class DenseASPP(nn.Module):
     def _get_backend(self):
         if self._backend is None:
             from .backend import HipBackend
-            self._backend = HipBackend()
+            self._backend = HipBackend(self.compute_dtype)
+            self._alloc_shadows()
         return self._backend
+
+    def set_compute_dtype(self, dtype):
+        """torch.bfloat16 (default: bf16 storage, bf16 MFMA, fp32 accumulation) or torch.float32 (fp32 storage
+        and arithmetic, eval-mode inference only: the form used to check the network against an fp32
+        reference to 1e-4)."""
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise TypeError('compute dtype must be torch.bfloat16 or torch.float32')
+        if dtype != self.compute_dtype:
+            self.compute_dtype = dtype
+            self._backend = None
+            self._engines = {}
+            self._wt_table = None
+        return self
 
     def set_backend(self, backend):
         """Test hook: run descriptor lists through another interpreter (CPU kernel model in tests/)."""

@@ -38,8 +38,18 @@ class Ref:
         return self.t.data_ptr() + self.off * self.t.element_size()
 
 
+# ops whose descriptor carries the activation storage type (include/dsaspp.h: `dtype`)
+_DTYPE_OPS = frozenset(('conv', 'bn_act', 'avgpool_fwd', 'im2col', 'maxpool_fwd', 'stem3', 'dwconv'))
+
+
 class OpList(list):
+    def __init__(self, dtype_code=0):
+        super().__init__()
+        self.dtype_code = dtype_code
+
     def op(self, kind, **fields):
+        if self.dtype_code and kind in _DTYPE_OPS:
+            fields['dtype'] = self.dtype_code
         self.append((kind, fields))
 
 
@@ -82,6 +92,10 @@ class Engine:
         dev = device
         f32, bf16 = torch.float32, backend.act_dtype
         self.act_dtype = bf16
+        self.dtype_code = 1 if backend.act_dtype == torch.float32 else 0
+        if self.dtype_code and training and getattr(backend, 'forward_only_fp32', False):
+            raise NotImplementedError('fp32 activation storage on the MI355X path covers eval-mode inference only; '
+                                      'train with the default bf16 storage')
 
         def zeros(n, dt=f32):
             return torch.zeros(int(n), dtype=dt, device=dev)
@@ -291,7 +305,7 @@ class Engine:
     # ------------------------------------------------------------------ forward
     def build_forward(self):
         sp, tr = self.spec, self.training
-        ops = OpList()
+        ops = OpList(self.dtype_code)
         B = self.B
         conv = dict(in_scale=None, in_shift=None, in_relu=0, in_mask=None, in_mask_ld=0, bias=None,
                     out_mask=None, out_mask_ld=0, y=None, ldy=0, y_f32=0, stat_acc=None, epi_relu=0, ref=None,
