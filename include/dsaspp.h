@@ -362,6 +362,43 @@ int dsaspp_upsample8_bwd(const dsaspp_up_desc* d, dsaspp_stream_t stream);
 int dsaspp_upsample8_argmax(const dsaspp_up_desc* d, dsaspp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Evaluation metric next to the path: bilinear x8 upsample + arg-max + confusion-matrix counts in one
+ * pass (replaces F.softmax + torch.argmax + the per-class Python loop with .item() syncs of
+ * evaluate_model, reference graph_seg_main.py:85-103, and get_iou, graph_seg_test.py:61-78).
+ *   conf: int64 [(n_class+1)][n_class], conf[r][p] += 1 for every full-resolution pixel with arg-max p and
+ *         label r; labels outside [0, n_class) (the ignore label 255) count in row n_class, because the
+ *         reference's union term counts predictions on ignored pixels too.
+ *   argmax: optional int64 [N][8h][8w] map of the arg-max classes.
+ */
+typedef struct dsaspp_conf_desc {
+    int32_t n_img, h, w, n_class, ldl;
+    const float* logits;      /* low-res NHWC fp32 class scores */
+    const int64_t* labels;    /* [N][8h][8w] */
+    int64_t* conf;
+    int64_t* argmax;
+} dsaspp_conf_desc;
+int dsaspp_upsample8_confusion(const dsaspp_conf_desc* d, dsaspp_stream_t stream);
+
+/* Input pre-processing in front of the path (replaces the numpy/torchvision steps of the data loader,
+ * reference graph_seg_dataloader.py:111-116,129-131 labelId -> trainId table, :136 /255, :177-180
+ * horizontal flip, :213-214 mean/std normalisation, :226-227 HWC -> CHW float / int64 labels):
+ *   x[n][c][y][x'] = (img[n][y][x][c] / 255 - mean_c) / std_c   with x' = W-1-x when hflip
+ *   labels[n][y][x'] = lut[label_ids[n][y][x]]                   (when label_ids != NULL)
+ * so that the host-to-device copy can be the 3 B/pixel image and 1 B/pixel label map. */
+typedef struct dsaspp_prep_desc {
+    int32_t n_img, H, W;
+    const uint8_t* img;       /* [N][H][W][3] bytes */
+    float* x;                 /* [N][3][H][W] fp32 */
+    float mean0, mean1, mean2;
+    float std0, std1, std2;
+    int32_t hflip;
+    const uint8_t* label_ids; /* [N][H][W] or NULL */
+    const uint8_t* lut;       /* [256] */
+    int64_t* labels;          /* [N][H][W] */
+} dsaspp_prep_desc;
+int dsaspp_preprocess(const dsaspp_prep_desc* d, dsaspp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Parameter-side kernels over the flat parameter arena (adjacent to the path:
  * torch.optim.Adam(weight_decay) + poly learning rate, reference graph_seg_main.py:186,241-245).
  */

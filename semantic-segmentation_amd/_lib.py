@@ -85,6 +85,8 @@ wt_entry = STRUCTS['dsaspp_wt_entry']
 generic_desc = STRUCTS['dsaspp_generic_desc']
 stem3_desc = STRUCTS['dsaspp_stem3_desc']
 dw_desc = STRUCTS['dsaspp_dw_desc']
+conf_desc = STRUCTS['dsaspp_conf_desc']
+prep_desc = STRUCTS['dsaspp_prep_desc']
 
 # op name -> (program op code, descriptor struct, direct entry point)
 OPS = {
@@ -110,6 +112,9 @@ OPS = {
     'copy2d_bf16': (ENUMS['DSASPP_OP_COPY2D_BF16'], generic_desc, None),
     'stem3': (ENUMS['DSASPP_OP_STEM3'], stem3_desc, 'dsaspp_stem3x3s2'),
     'dwconv': (ENUMS['DSASPP_OP_DWCONV'], dw_desc, 'dsaspp_dwconv3x3'),
+    # direct calls only (not recordable in a program)
+    'confusion': (None, conf_desc, 'dsaspp_upsample8_confusion'),
+    'preprocess': (None, prep_desc, 'dsaspp_preprocess'),
 }
 
 _lib = None

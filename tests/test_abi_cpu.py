@@ -23,13 +23,14 @@ def test_descriptor_sizes_agree_with_library():
     lib = _lib.load()
     h = lib.dsaspp_program_create()
     try:
-        for kind, (code, struct, _) in _lib.OPS.items():
+        recordable = {k: v for k, v in _lib.OPS.items() if v[0] is not None}
+        for kind, (code, struct, _) in recordable.items():
             d = struct()
             # wrong size must be rejected with a message, right size accepted
             assert lib.dsaspp_program_add(h, code, ctypes.byref(d), ctypes.sizeof(d) + 8) != 0
             assert b'header mismatch' in lib.dsaspp_last_error()
             assert lib.dsaspp_program_add(h, code, ctypes.byref(d), ctypes.sizeof(d)) == 0, kind
-        assert lib.dsaspp_program_size(h) == len(_lib.OPS)
+        assert lib.dsaspp_program_size(h) == len(recordable)
     finally:
         lib.dsaspp_program_destroy(h)
 
@@ -44,3 +45,24 @@ def test_argument_validation_without_gpu():
     d.cin, d.taps = 16, 4
     assert lib.dsaspp_conv_fwd(ctypes.byref(d), None) != 0
     assert b'taps' in lib.dsaspp_last_error()
+
+
+def test_new_entry_points_validate_without_gpu():
+    from semantic_segmentation_amd import _lib
+    lib = _lib.load()
+    d = _lib.dw_desc()
+    d.n_img, d.H, d.W, d.C, d.stride, d.dil = 1, 8, 8, 12, 1, 1          # C not a multiple of 8
+    assert lib.dsaspp_dwconv3x3(ctypes.byref(d), None) != 0
+    assert b'multiple of 8' in lib.dsaspp_last_error()
+    s3 = _lib.stem3_desc()
+    s3.n_img, s3.H, s3.W, s3.cout = 1, 7, 8, 32                           # odd height
+    assert lib.dsaspp_stem3x3s2(ctypes.byref(s3), None) != 0
+    assert b'even' in lib.dsaspp_last_error()
+    c = _lib.conf_desc()
+    c.n_img, c.h, c.w, c.n_class, c.ldl = 1, 4, 4, 40, 40                 # too many classes
+    assert lib.dsaspp_upsample8_confusion(ctypes.byref(c), None) != 0
+    assert b'n_class' in lib.dsaspp_last_error()
+    p = _lib.prep_desc()
+    p.n_img, p.H, p.W = 1, 4, 6                                           # width not a multiple of 4
+    assert lib.dsaspp_preprocess(ctypes.byref(p), None) != 0
+    assert b'multiple of 4' in lib.dsaspp_last_error()
