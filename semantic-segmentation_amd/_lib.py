@@ -13,7 +13,8 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'dsaspp.h')
-LIB_PATH = os.path.join(HERE, 'libdsaspp.so')
+# DSASPP_LIB_PATH: measure another build of the same library (kernel A/B experiments); default is the in-tree build
+LIB_PATH = os.environ.get('DSASPP_LIB_PATH') or os.path.join(HERE, 'libdsaspp.so')
 
 _SCALARS = {
     'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float,

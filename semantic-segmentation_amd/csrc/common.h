@@ -44,7 +44,26 @@ __device__ __forceinline__ uint32_t f2bf_bits(float f) {
     __bf16 b = (__bf16)f;  // round-to-nearest-even, NaN preserving (v_cvt_pk_bf16_f32)
     return (uint32_t)__builtin_bit_cast(u16, b);
 }
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return f2bf_bits(lo) | (f2bf_bits(hi) << 16); }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) short i16x2_t;
+// two floats -> packed bf16 pair, round-to-nearest-even: ONE v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+// ReLU on a packed bf16 pair as a signed 16-bit max (v_pk_max_i16): bf16 values with the sign bit set are
+// negative as int16 too.  floor_bits = 0 applies the ReLU, 0x80008000 (INT16_MIN twice) leaves the pair as it is,
+// so the choice costs no branch.  Rounding is monotonic and keeps the sign: relu(round(x)) == round(relu(x)).
+__device__ __forceinline__ uint32_t relu_bf2(uint32_t v, uint32_t floor_bits) {
+    const i16x2_t a = __builtin_bit_cast(i16x2_t, v), f = __builtin_bit_cast(i16x2_t, floor_bits);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(a, f));
+}
+__device__ __forceinline__ uint4 relu_bf8(uint4 v, uint32_t floor_bits) {
+    v.x = relu_bf2(v.x, floor_bits); v.y = relu_bf2(v.y, floor_bits);
+    v.z = relu_bf2(v.z, floor_bits); v.w = relu_bf2(v.w, floor_bits);
+    return v;
+}
 __device__ __forceinline__ float bf_round(float f) { return __uint_as_float(f2bf_bits(f) << 16); }
 
 // 8 bf16 (one 16-byte chunk) <-> 8 floats

@@ -96,8 +96,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const dsaspp_conv_d
             float f[8];
             unpack8(v[u], f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = fmaxf(fmaf(f[e], sc[e], sh[e]), relu_floor);
-            uint4 o = pack8(f);
+            for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+            uint4 o = relu_bf8(pack8(f), d.in_relu ? 0u : 0x80008000u);     // ReLU after the rounding (packed 16-bit max)
             const bool k = (okmask >> u) & 1u;          // zero padding comes after BatchNorm + ReLU
             o.x = k ? o.x : 0u; o.y = k ? o.y : 0u; o.z = k ? o.z : 0u; o.w = k ? o.w : 0u;
             const int pix = (tid >> 3) + u * (NT / 8);

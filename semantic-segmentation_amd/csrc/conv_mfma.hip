@@ -43,10 +43,19 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
     constexpr int TP = BP / WP, TQ = BQ / WQ, MP = TP / 16, MQ = TQ / 16;
     static_assert(TP % 16 == 0 && TQ % 16 == 0, "wave tile");
 
+    // 8-wave tiles: the weight tile needs no prologue, so it goes global -> LDS by DMA (global_load_lds) into a
+    // ring of two buffers, one K-step ahead; that takes three of the five 16-byte register->LDS stores per lane
+    // and K-step (the slowest LDS operation there is) and their staging registers out of the loop.
+#ifndef DSASPP_DMAW
+#define DSASPP_DMAW 1
+#endif
+    constexpr bool DMAW = (NW == 8) && (DSASPP_DMAW != 0);
+    constexpr int NWB = DMAW ? 2 : 1;             // weight buffers
+    static_assert(!DMAW || BQ % 64 == 0, "DMA weight tile: 8 waves x 8 rows per pass");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;
     unsigned char* Ws = smem + A_BYTES;
-    float* tab = reinterpret_cast<float*>(smem + A_BYTES + W_BYTES);
+    float* tab = reinterpret_cast<float*>(smem + A_BYTES + NWB * W_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = xcd_remap(blockIdx.x, nblocks);
@@ -67,6 +76,7 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
     }
     const float relu_floor = d.in_relu ? 0.f : -3.0e38f;
     const float relu_ceil = (d.in_relu == 2) ? 6.f : 3.0e38f;     // ReLU6: general prologue (PRO == 2) only
+    const uint32_t relu_bits = d.in_relu ? 0u : 0x80008000u;      // see relu_bf2
 
     // ---- per-thread staging coordinates: chunk column ck of rows (tid>>3) + RSTEP*i
     const int ck = tid & 7;
@@ -87,16 +97,28 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
     const u16* wg = reinterpret_cast<const u16*>(d.w);
     const u16* w_ptr[WR];
     bool w_ok[WR];
+    int wd_chunk[WR];                   // DMA form: source chunk of this lane (the XOR swizzle lives in the source address)
     auto w_setup = [&]() {
 #pragma unroll
         for (int i = 0; i < WR; ++i) {
-            const int idx = tid + NT * i;
-            const int row = idx >> 3;
-            w_ok[i] = (idx < WCH) && (q_base + row < cout);
-            w_ptr[i] = wg + (w_ok[i] ? (int64_t)(q_base + row) * Ktot : 0);
+            if (DMAW) {
+                // wave-instruction i of this wave fills LDS rows (i*8 + wave)*8 .. +7, lane-linear: lane -> (row, slot)
+                const int row = (i * 8 + wave) * 8 + (lane >> 3);
+                int q = q_base + row;
+                q = q < cout ? q : cout - 1;          // rows past cout: any finite data, their results are never stored
+                w_ptr[i] = wg + (int64_t)q * Ktot;
+                wd_chunk[i] = ((lane & 7) ^ swz8(row)) * 8;
+                w_ok[i] = true;
+            } else {
+                const int idx = tid + NT * i;
+                const int row = idx >> 3;
+                w_ok[i] = (idx < WCH) && (q_base + row < cout);
+                w_ptr[i] = wg + (w_ok[i] ? (int64_t)(q_base + row) * Ktot : 0);
+            }
         }
     };
     w_setup();
+    int wbuf = 0;                       // ring slot the next weight DMA fills
 
     // per-tap row pointers (recomputed only when the tap changes)
     const u16* a_ptr[AR];
@@ -132,13 +154,27 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
             areg[i] = *reinterpret_cast<const uint4*>(a_ptr[i] + co);     // always a mapped address
             lval[i] = a_val[i] && cvalid;
         }
-        const int ko = cvalid ? tap * cin + c : 0;
+        if (DMAW) {
+            typedef __attribute__((address_space(3))) void* lds_p;
+            typedef const __attribute__((address_space(1))) void* glb_p;
+            unsigned char* slot = Ws + wbuf * W_BYTES;
 #pragma unroll
-        for (int i = 0; i < WR; ++i) {
-            // raw load only: touching the value here would make the wave wait for it before the MFMAs of the
-            // step in progress; out-of-range rows / the K tail are zeroed when the chunk goes to LDS
-            wreg[i] = *reinterpret_cast<const uint4*>(w_ptr[i] + ko);
-            wval[i] = w_ok[i] && cvalid;
+            for (int i = 0; i < WR; ++i) {
+                // K tail: the activation chunk is zeroed, so the weight chunk only has to be finite -> channel 0
+                const int cc = c0 + wd_chunk[i];
+                const int kq = cc < cin ? tap * cin + cc : 0;
+                __builtin_amdgcn_global_load_lds((glb_p)(w_ptr[i] + kq), (lds_p)(slot + (i * 8 + wave) * 1024), 16, 0, 0);
+            }
+            wbuf ^= 1;
+        } else {
+            const int ko = cvalid ? tap * cin + c : 0;
+#pragma unroll
+            for (int i = 0; i < WR; ++i) {
+                // raw load only: touching the value here would make the wave wait for it before the MFMAs of the
+                // step in progress; out-of-range rows / the K tail are zeroed when the chunk goes to LDS
+                wreg[i] = *reinterpret_cast<const uint4*>(w_ptr[i] + ko);
+                wval[i] = w_ok[i] && cvalid;
+            }
         }
         lc = co;
         c0 += BK;
@@ -165,19 +201,19 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], relu_floor);
                 if (PRO == 2) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = fminf(f[e], relu_ceil);
-                }
-                if (PRO == 2 && d.in_mask) {
-                    float mk[8];
-                    load8f(d.in_mask + (int64_t)a_n[i] * d.in_mask_ld + lc, mk);
+                    for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(f[e], relu_floor), relu_ceil);
+                    if (d.in_mask) {
+                        float mk[8];
+                        load8f(d.in_mask + (int64_t)a_n[i] * d.in_mask_ld + lc, mk);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] *= mk[e];
+                        for (int e = 0; e < 8; ++e) f[e] *= mk[e];
+                    }
+                    v = pack8(f);
+                } else {
+                    v = relu_bf8(pack8(f), relu_bits);     // ReLU after the rounding, four packed 16-bit max
                 }
-                v = pack8(f);
             }
             const bool ok = lval[i];      // zero padding (halo, K tail, rows past M) comes AFTER the prologue
             v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
@@ -185,7 +221,7 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
             *reinterpret_cast<uint4*>(As + row * 128 + ((ck ^ swz8(row)) << 4)) = v;
         }
 #pragma unroll
-        for (int i = 0; i < WR; ++i) {
+        for (int i = 0; i < (DMAW ? 0 : WR); ++i) {
             const int idx = tid + NT * i;
             if (idx < WCH) {
                 const int row = idx >> 3;
@@ -211,13 +247,18 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
     auto run_k = [&]() {
         tap = 0;
         c0 = 0;
+        wbuf = 0;
         tap_setup(0);
         gload();
         __syncthreads();   // scale/shift table visible
         for (int s = 0; s < ksteps; ++s) {
             sstore();                              // K-step s: registers -> LDS (prologue applied here)
+            if (DMAW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's weight DMAs of step s have landed
             __syncthreads();
-            if (s + 1 < ksteps) gload();           // K-step s+1 in flight while step s is multiplied
+            // K-step s+1 in flight while step s is multiplied; its weight DMA fills the buffer last read in step
+            // s-1, which every wave left before the barrier that ended that step
+            if (s + 1 < ksteps) gload();
+            const unsigned char* Wc = Ws + (DMAW ? (s & 1) * W_BYTES : 0);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int fo = ks ? frag_off1 : frag_off0;
@@ -227,14 +268,18 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
                     af[j] = *reinterpret_cast<const bf16x8*>(As + (wp * TP + j * 16) * 128 + fo);
 #pragma unroll
                 for (int i = 0; i < MQ; ++i)
-                    wf[i] = *reinterpret_cast<const bf16x8*>(Ws + (wq * TQ + i * 16) * 128 + fo);
+                    wf[i] = *reinterpret_cast<const bf16x8*>(Wc + (wq * TQ + i * 16) * 128 + fo);
 #pragma unroll
                 for (int i = 0; i < MQ; ++i)
 #pragma unroll
                     for (int j = 0; j < MP; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
             }
-            __syncthreads();                       // every wave is done reading before the next store
+            // every wave is done reading before the next store.  Not __syncthreads(): that also waits for
+            // vmcnt(0), i.e. for the loads of step s+1 that were just put in flight.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
     };
     const int rep = blockIdx.x % DS_R;
@@ -348,7 +393,7 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
     constexpr int NCB = TQ / CBW;
     constexpr int NRP = 16 / RPP;
     constexpr int ROWF = TQ + 4;                    // padded row stride in floats (bank spread)
-    static_assert(NW * 16 * ROWF * 4 + 7 * BQ * 4 <= A_BYTES + W_BYTES, "epilogue LDS fits in the staging buffers");
+    static_assert(NW * 16 * ROWF * 4 + 7 * BQ * 4 <= A_BYTES + NWB * W_BYTES, "epilogue LDS fits in the staging buffers");
     float* stage = reinterpret_cast<float*>(smem) + wave * (16 * ROWF);
     float* epar = reinterpret_cast<float*>(smem) + NW * 16 * ROWF;     // [5][BQ]: bias, scale, shift, mean, rstd
     float* red = epar + 5 * BQ;                                        // [2][BQ]: block-level sums
@@ -528,7 +573,7 @@ int launch_mode(const dsaspp_conv_desc& d, hipStream_t s) {
     const int M = (int)M64;
     const int nP = (M + BP - 1) / BP, nQ = (d.cout + BQ - 1) / BQ;
     const int nblocks = nP * nQ;
-    const size_t lds = (size_t)(BP + BQ) * BK * 2 + ((PRO != 0 && d.in_scale) ? (size_t)d.cin * 8 : 0) + (EPI == 3 ? (size_t)BQ * 8 : 0);
+    const size_t lds = (size_t)(BP + BQ * ((WP * WQ == 8 && DSASPP_DMAW != 0) ? 2 : 1)) * BK * 2 + ((PRO != 0 && d.in_scale) ? (size_t)d.cin * 8 : 0) + (EPI == 3 ? (size_t)BQ * 8 : 0);
     DS_REQUIRE(lds <= 160 * 1024, "conv_fwd: LDS request %zu too large", lds);
     auto kern = conv_kernel<BP, BQ, WP, WQ, PRO, EPI>;
     if (lds > 64 * 1024) {

@@ -168,15 +168,17 @@ __global__ __launch_bounds__(64 * WQ * WC * KG, (WQ * WC == 8) ? 4 : 2) void wgr
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], relu_floor);
                 if (PRO == 2 && d.in_mask) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], relu_floor);
                     float mk[8];
                     load8f(d.in_mask + (int64_t)ximg[i] * d.in_mask_ld + (xc_ok ? c_base + xc * 8 : 0), mk);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] *= mk[e];
+                    v = pack8(f);
+                } else {
+                    v = relu_bf8(pack8(f), d.in_relu ? 0u : 0x80008000u);     // ReLU after the rounding (packed 16-bit max)
                 }
-                v = pack8(f);
             }
             const bool ok = xval[i];       // zero padding comes after the prologue
             v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;

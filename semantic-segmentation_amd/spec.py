@@ -57,8 +57,8 @@ class IRBlockSpec:
 class NetSpec:
     kind = 'densenet'
 
-    def __new__(cls, cfg, n_class=19, output_stride=8):
-        if cls is NetSpec and is_mobilenet_cfg(cfg):
+    def __new__(cls, cfg=None, n_class=19, output_stride=8):
+        if cls is NetSpec and cfg is not None and is_mobilenet_cfg(cfg):
             return object.__new__(MobileNetSpec)
         return object.__new__(cls)
 
