@@ -30,7 +30,7 @@ __device__ __forceinline__ int swz8(int row) { return (row >> 1) & 7; }
 // EPI selects the epilogue: 0 = plain store (+bias, +dropout mask, +statistics), 1 = store masked by a
 // reference pre-activation with BatchNorm-backward sums (3x3 data gradient), 2 = gradient-slab store/accumulate.
 template <int BP, int BQ, int WP, int WQ, int PRO, int EPI>
-__global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_kernel(const dsaspp_conv_desc d, const int M,
+__global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8 && BP < 256) ? 4 : 2) void conv_kernel(const dsaspp_conv_desc d, const int M,
                                                                                   const int nQ, const int nblocks) {
     constexpr int NW = WP * WQ, NT = 64 * NW;     // waves / threads per block
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
@@ -49,7 +49,11 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
 #ifndef DSASPP_DMAW
 #define DSASPP_DMAW 1
 #endif
-    constexpr bool DMAW = (NW == 8) && (DSASPP_DMAW != 0);
+    // BIG: 256-pixel tile, one block per CU with 256 registers per lane.  Its operands all travel through
+    // registers (no DMA) so that the compiler's vmcnt bookkeeping stays exact -- an outstanding LDS-DMA makes it
+    // wait for vmcnt(0) at the next use of any loaded register -- and the activation loads run two K-steps ahead.
+    constexpr bool BIG = (BP >= 256) && (NW == 8);
+    constexpr bool DMAW = (NW == 8) && !BIG && (DSASPP_DMAW != 0);
     constexpr int NWB = DMAW ? 2 : 1;             // weight buffers
     static_assert(!DMAW || BQ % 64 == 0, "DMA weight tile: 8 waves x 8 rows per pass");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -140,43 +144,24 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
         }
     };
 
-    uint4 areg[AR], wreg[WR];
-    bool lval[AR], wval[WR];            // validity of the chunks held in areg / wreg
-    int lc = 0;                         // channel of the chunks held in areg (for the prologue tables)
-    int tap = 0, c0 = 0;                // position of the next K-step to load
+    // Activation chunks travel through registers (the prologue is applied on their way to LDS), PD K-steps ahead.
+    constexpr int PD = BIG ? 2 : 1;
+    uint4 areg[PD][AR], wreg[WR];
+    bool lval[PD][AR], wval[WR];        // validity of the chunks held in areg / wreg
+    int lc[PD];                         // channel of the chunks held in areg (for the prologue tables)
+    int tap = 0, c0 = 0;                // activation cursor: position of the next K-step to load
+    int tapw = 0, c0w = 0;              // weight cursor
 
-    auto gload = [&]() {
+    auto loadA = [&](const int st) {
         const int c = c0 + ck * 8;
         const bool cvalid = c < cin;
         const int co = cvalid ? c : 0;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            areg[i] = *reinterpret_cast<const uint4*>(a_ptr[i] + co);     // always a mapped address
-            lval[i] = a_val[i] && cvalid;
+            areg[st][i] = *reinterpret_cast<const uint4*>(a_ptr[i] + co);     // always a mapped address
+            lval[st][i] = a_val[i] && cvalid;
         }
-        if (DMAW) {
-            typedef __attribute__((address_space(3))) void* lds_p;
-            typedef const __attribute__((address_space(1))) void* glb_p;
-            unsigned char* slot = Ws + wbuf * W_BYTES;
-#pragma unroll
-            for (int i = 0; i < WR; ++i) {
-                // K tail: the activation chunk is zeroed, so the weight chunk only has to be finite -> channel 0
-                const int cc = c0 + wd_chunk[i];
-                const int kq = cc < cin ? tap * cin + cc : 0;
-                __builtin_amdgcn_global_load_lds((glb_p)(w_ptr[i] + kq), (lds_p)(slot + (i * 8 + wave) * 1024), 16, 0, 0);
-            }
-            wbuf ^= 1;
-        } else {
-            const int ko = cvalid ? tap * cin + c : 0;
-#pragma unroll
-            for (int i = 0; i < WR; ++i) {
-                // raw load only: touching the value here would make the wave wait for it before the MFMAs of the
-                // step in progress; out-of-range rows / the K tail are zeroed when the chunk goes to LDS
-                wreg[i] = *reinterpret_cast<const uint4*>(w_ptr[i] + ko);
-                wval[i] = w_ok[i] && cvalid;
-            }
-        }
-        lc = co;
+        lc[st] = co;
         c0 += BK;
         if (c0 >= cin) {
             c0 = 0;
@@ -185,15 +170,47 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
         }
     };
 
-    auto sstore = [&]() {
+    auto loadW = [&]() {
+        if (DMAW) {
+            typedef __attribute__((address_space(3))) void* lds_p;
+            typedef const __attribute__((address_space(1))) void* glb_p;
+            unsigned char* slot = Ws + wbuf * W_BYTES;
+#pragma unroll
+            for (int i = 0; i < WR; ++i) {
+                // K tail: the activation chunk is zeroed, so the weight chunk only has to be finite -> channel 0
+                const int cc = c0w + wd_chunk[i];
+                const int kq = cc < cin ? tapw * cin + cc : 0;
+                __builtin_amdgcn_global_load_lds((glb_p)(w_ptr[i] + kq), (lds_p)(slot + (i * 8 + wave) * 1024), 16, 0, 0);
+            }
+            wbuf ^= 1;
+        } else {
+            const int c = c0w + ck * 8;
+            const bool cvalid = c < cin;
+            const int ko = cvalid ? tapw * cin + c : 0;
+#pragma unroll
+            for (int i = 0; i < WR; ++i) {
+                // raw load only: touching the value here would make the wave wait for it before the MFMAs of the
+                // step in progress; out-of-range rows / the K tail are zeroed when the chunk goes to LDS
+                wreg[i] = *reinterpret_cast<const uint4*>(w_ptr[i] + ko);
+                wval[i] = w_ok[i] && cvalid;
+            }
+        }
+        c0w += BK;
+        if (c0w >= cin) {
+            c0w = 0;
+            ++tapw;
+        }
+    };
+
+    auto sstore = [&](const int st) {
         float sc[8], sh[8];
         if (PRO == 1 || (PRO == 2 && has_scale)) {
-            load8f(tab + lc, sc);
-            load8f(tab + cin + lc, sh);
+            load8f(tab + lc[st], sc);
+            load8f(tab + cin + lc[st], sh);
         }
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            uint4 v = areg[i];
+            uint4 v = areg[st][i];
             if (PRO != 0) {
                 float f[8];
                 unpack8(v, f);
@@ -206,7 +223,7 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
                     for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(f[e], relu_floor), relu_ceil);
                     if (d.in_mask) {
                         float mk[8];
-                        load8f(d.in_mask + (int64_t)a_n[i] * d.in_mask_ld + lc, mk);
+                        load8f(d.in_mask + (int64_t)a_n[i] * d.in_mask_ld + lc[st], mk);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) f[e] *= mk[e];
                     }
@@ -215,7 +232,7 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
                     v = relu_bf8(pack8(f), relu_bits);     // ReLU after the rounding, four packed 16-bit max
                 }
             }
-            const bool ok = lval[i];      // zero padding (halo, K tail, rows past M) comes AFTER the prologue
+            const bool ok = lval[st][i];  // zero padding (halo, K tail, rows past M) comes AFTER the prologue
             v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
             const int row = arow0 + RSTEP * i;
             *reinterpret_cast<uint4*>(As + row * 128 + ((ck ^ swz8(row)) << 4)) = v;
@@ -244,42 +261,54 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8) ? 4 : 2) void conv_ker
 #pragma unroll
         for (int j = 0; j < MP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // block barrier that waits for this wave's LDS operations only: __syncthreads() also drains vmcnt, i.e.
+    // it would wait for the prefetches that are meant to stay in flight
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
     auto run_k = [&]() {
-        tap = 0;
-        c0 = 0;
+        tap = 0; c0 = 0; tapw = 0; c0w = 0;
         wbuf = 0;
         tap_setup(0);
-        gload();
+        loadW();                                   // weights of step 0
+        loadA(0);
+        if (PD > 1 && ksteps > 1) loadA(1);
         __syncthreads();   // scale/shift table visible
-        for (int s = 0; s < ksteps; ++s) {
-            sstore();                              // K-step s: registers -> LDS (prologue applied here)
-            if (DMAW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's weight DMAs of step s have landed
-            __syncthreads();
-            // K-step s+1 in flight while step s is multiplied; its weight DMA fills the buffer last read in step
-            // s-1, which every wave left before the barrier that ended that step
-            if (s + 1 < ksteps) gload();
-            const unsigned char* Wc = Ws + (DMAW ? (s & 1) * W_BYTES : 0);
+        for (int s = 0; s < ksteps; s += PD) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int fo = ks ? frag_off1 : frag_off0;
-                bf16x8 af[MP], wf[MQ];
+            for (int u = 0; u < PD; ++u) {
+                const int ss = s + u;
+                if (ss < ksteps) {
+                    sstore(u);                     // K-step ss: registers -> LDS (prologue applied here)
+                    if (DMAW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's weight DMAs of step ss have landed
+                    lds_barrier();
+                    // weights one step ahead (a DMA fills the slot last read in step ss-1, which every wave left
+                    // before the barrier that ended that step), activations PD steps ahead
+                    if (ss + 1 < ksteps) loadW();
+                    if (ss + PD < ksteps) loadA(u);
+                    const unsigned char* Wc = Ws + (DMAW ? (ss & 1) * W_BYTES : 0);
 #pragma unroll
-                for (int j = 0; j < MP; ++j)
-                    af[j] = *reinterpret_cast<const bf16x8*>(As + (wp * TP + j * 16) * 128 + fo);
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int fo = ks ? frag_off1 : frag_off0;
+                        bf16x8 af[MP], wf[MQ];
 #pragma unroll
-                for (int i = 0; i < MQ; ++i)
-                    wf[i] = *reinterpret_cast<const bf16x8*>(Wc + (wq * TQ + i * 16) * 128 + fo);
+                        for (int j = 0; j < MP; ++j)
+                            af[j] = *reinterpret_cast<const bf16x8*>(As + (wp * TP + j * 16) * 128 + fo);
 #pragma unroll
-                for (int i = 0; i < MQ; ++i)
+                        for (int i = 0; i < MQ; ++i)
+                            wf[i] = *reinterpret_cast<const bf16x8*>(Wc + (wq * TQ + i * 16) * 128 + fo);
 #pragma unroll
-                    for (int j = 0; j < MP; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                        for (int i = 0; i < MQ; ++i)
+#pragma unroll
+                            for (int j = 0; j < MP; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                    }
+                    lds_barrier();                 // every wave is done reading before the next store
+                }
             }
-            // every wave is done reading before the next store.  Not __syncthreads(): that also waits for
-            // vmcnt(0), i.e. for the loads of step s+1 that were just put in flight.
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
         }
     };
     const int rep = blockIdx.x % DS_R;
@@ -573,7 +602,7 @@ int launch_mode(const dsaspp_conv_desc& d, hipStream_t s) {
     const int M = (int)M64;
     const int nP = (M + BP - 1) / BP, nQ = (d.cout + BQ - 1) / BQ;
     const int nblocks = nP * nQ;
-    const size_t lds = (size_t)(BP + BQ * ((WP * WQ == 8 && DSASPP_DMAW != 0) ? 2 : 1)) * BK * 2 + ((PRO != 0 && d.in_scale) ? (size_t)d.cin * 8 : 0) + (EPI == 3 ? (size_t)BQ * 8 : 0);
+    const size_t lds = (size_t)(BP + BQ * ((WP * WQ == 8 && BP < 256 && DSASPP_DMAW != 0) ? 2 : 1)) * BK * 2 + ((PRO != 0 && d.in_scale) ? (size_t)d.cin * 8 : 0) + (EPI == 3 ? (size_t)BQ * 8 : 0);
     DS_REQUIRE(lds <= 160 * 1024, "conv_fwd: LDS request %zu too large", lds);
     auto kern = conv_kernel<BP, BQ, WP, WQ, PRO, EPI>;
     if (lds > 64 * 1024) {
@@ -667,6 +696,7 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
                 case 5: return launch<64, 128, 1, 4>(d, s);
                 case 6: return launch<64, 192, 1, 4>(d, s);
                 case 8: return launch<128, 64, 2, 2>(d, s);
+                case 9: return launch<256, 192, 4, 2>(d, s);
                 default: break;
             }
         }
