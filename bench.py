@@ -163,7 +163,9 @@ def main():
         traffic = None                                  # HBM bytes per launch from the committed PMC passes, if any
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
         if os.path.exists(tpath):
-            traffic = (json.load(open(tpath)).get(dom) or {}).get('hbm_bytes_per_launch')
+            tj = json.load(open(tpath))
+            if (tj.get('_meta') or {}).get('batch') == args.batch:      # bytes per launch scale with the batch
+                traffic = (tj.get(dom) or {}).get('hbm_bytes_per_launch')
         roofline = dict(bound='mfma', kernel=dom, achieved=round(mfma[dom]['tflops'], 2), peak=PEAK_BF16_TFLOPS,
                         unit='TFLOP/s', frac=round(mfma[dom]['tflops'] / PEAK_BF16_TFLOPS, 4), traffic=traffic,
                         avg_launch_us=round(mfma[dom]['avg_us'], 2), launches_per_step=mfma[dom]['launches_per_step'])
