@@ -75,6 +75,12 @@ def main():
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: libraries that print to fd 1 (RCCL writes a version banner there when a
+    # communicator is created) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -192,7 +198,8 @@ def main():
             out['cpu_baseline'] = cpu_baseline(cfg)
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if world > 1 or args.force_reducer:
         dist.destroy_process_group()
 
