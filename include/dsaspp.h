@@ -254,6 +254,27 @@ int dsaspp_avgpool2_fwd(const dsaspp_pool_desc* d, dsaspp_stream_t stream);
 /* dx[n][h][w][c] = dy[n][h/2][w/2][c] / 4 ; here x is the gradient OUTPUT (full size), y the INPUT */
 int dsaspp_avgpool2_bwd(const dsaspp_pool_desc* d, dsaspp_stream_t stream);
 
+/* Bilinear x2 upsample (align_corners=False) of an NHWC feature map, the `upsample` stage that follows
+ * features.norm5 when output_stride = 16 (upstream DenseASPP(model_cfg, n_class, output_stride) constructor;
+ * reference call site graph_seg_test.py:129), fused with that BatchNorm and the ReLU heading ASPP_3:
+ *   fwd: y[n][Y][X][c] = act(scale[c] * interp2(x)[n][Y][X][c] + shift[c])   (interpolation weights sum to 1, so the
+ *        affine map commutes with it); optional statistics of the stored values
+ *   bwd: dx[n][y][x][c] = sum over the <= 3x3 outputs that read (y, x) of weight * dy ; optional BatchNorm-backward
+ *        sums s_acc += {dx, dx * (yref - mean) * rstd}, yref being the low-resolution forward input
+ * x / dx are [N*h*w][ld], y / dy are [N*2h*2w][ld]. */
+typedef struct dsaspp_up2_desc {
+    int32_t n_img, h, w, C;   /* low-resolution geometry */
+    const void* x; int32_t ldx;           /* fwd: input ; bwd: yref (may be NULL when s_acc is NULL) */
+    const float* scale; const float* shift; int32_t relu;   /* fwd only */
+    void* y; int32_t ldy;                 /* fwd: output ; bwd: dy (input) */
+    float* stat_acc;                      /* fwd: [R][2*C] or NULL */
+    void* dx; int32_t lddx; int32_t dx_f32;   /* bwd output (bf16, or fp32 when dx_f32) */
+    const float* mean; const float* rstd; float* s_acc;     /* bwd: BatchNorm-backward sums [R][2*C] or NULL */
+    int32_t dtype;            /* fwd: 0 = bf16, 1 = fp32 storage (eval-mode forward only) */
+} dsaspp_up2_desc;
+int dsaspp_upsample2_fwd(const dsaspp_up2_desc* d, dsaspp_stream_t stream);
+int dsaspp_upsample2_bwd(const dsaspp_up2_desc* d, dsaspp_stream_t stream);
+
 /* Stem: 7x7/2 im2col of the NCHW fp32 network input to bf16 rows [N*Ho*Wo][ldcol]
  * (K order (ky,kx,ci), zero padded), so conv0 runs as a 1x1 GEMM; and the
  * BN+ReLU -> 3x3/2 max pooling that follows, with its backward. */
@@ -447,7 +468,8 @@ enum {
     DSASPP_OP_BN_ACT, DSASPP_OP_GRAD_EXTRACT, DSASPP_OP_BN_BWD_APPLY, DSASPP_OP_AVGPOOL_FWD,
     DSASPP_OP_AVGPOOL_BWD, DSASPP_OP_IM2COL, DSASPP_OP_MAXPOOL_FWD, DSASPP_OP_MAXPOOL_BWD,
     DSASPP_OP_UPCE, DSASPP_OP_CE_FINALIZE, DSASPP_OP_UP_FWD, DSASPP_OP_UP_BWD, DSASPP_OP_UP_ARGMAX,
-    DSASPP_OP_MEMSET, DSASPP_OP_COPY2D, DSASPP_OP_COPY2D_BF16, DSASPP_OP_STEM3, DSASPP_OP_DWCONV
+    DSASPP_OP_MEMSET, DSASPP_OP_COPY2D, DSASPP_OP_COPY2D_BF16, DSASPP_OP_STEM3, DSASPP_OP_DWCONV,
+    DSASPP_OP_UP2_FWD, DSASPP_OP_UP2_BWD
 };
 dsaspp_program* dsaspp_program_create(void);
 void dsaspp_program_destroy(dsaspp_program* p);

@@ -88,6 +88,7 @@ stem3_desc = STRUCTS['dsaspp_stem3_desc']
 dw_desc = STRUCTS['dsaspp_dw_desc']
 conf_desc = STRUCTS['dsaspp_conf_desc']
 prep_desc = STRUCTS['dsaspp_prep_desc']
+up2_desc = STRUCTS['dsaspp_up2_desc']
 
 # op name -> (program op code, descriptor struct, direct entry point)
 OPS = {
@@ -113,6 +114,8 @@ OPS = {
     'copy2d_bf16': (ENUMS['DSASPP_OP_COPY2D_BF16'], generic_desc, None),
     'stem3': (ENUMS['DSASPP_OP_STEM3'], stem3_desc, 'dsaspp_stem3x3s2'),
     'dwconv': (ENUMS['DSASPP_OP_DWCONV'], dw_desc, 'dsaspp_dwconv3x3'),
+    'up2_fwd': (ENUMS['DSASPP_OP_UP2_FWD'], up2_desc, 'dsaspp_upsample2_fwd'),
+    'up2_bwd': (ENUMS['DSASPP_OP_UP2_BWD'], up2_desc, 'dsaspp_upsample2_bwd'),
     # direct calls only (not recordable in a program)
     'confusion': (None, conf_desc, 'dsaspp_upsample8_confusion'),
     'preprocess': (None, prep_desc, 'dsaspp_preprocess'),

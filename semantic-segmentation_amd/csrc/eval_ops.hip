@@ -122,3 +122,194 @@ extern "C" int dsaspp_preprocess(const dsaspp_prep_desc* d, dsaspp_stream_t stre
     DS_LAUNCH_CHECK("preprocess");
     return 0;
 }
+
+// ---------------------------------------------------------------- bilinear x2 upsample of a feature map (output stride 16)
+namespace {
+
+// source rows/columns and weights of output index o (align_corners=False, scale 2): even o = 2k reads (k-1, k) with
+// weights (0.25, 0.75), odd o = 2k+1 reads (k, k+1) with (0.75, 0.25); indices clamp at the border.
+__device__ __forceinline__ void src2(int o, int n, int& i0, int& i1, float& w1) {
+    float s = 0.5f * ((float)o + 0.5f) - 0.5f;
+    s = fmaxf(s, 0.f);
+    i0 = (int)s;
+    i1 = i0 + (i0 < n - 1 ? 1 : 0);
+    w1 = s - (float)i0;
+}
+
+template <bool F32>
+__device__ __forceinline__ void ld8(const void* base, int64_t elem, float (&f)[8]) {
+    if (F32) {
+        load8f(reinterpret_cast<const float*>(base) + elem, f);
+    } else {
+        unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(base) + elem), f);
+    }
+}
+
+template <int CGB, bool F32>
+__global__ __launch_bounds__(256) void up2_fwd_kernel(const dsaspp_up2_desc d) {
+    __shared__ float red[256 * 16];
+    constexpr int RB = 256 / CGB;
+    const int cx = threadIdx.x % CGB, ry = threadIdx.x / CGB;
+    const int c = (blockIdx.x * CGB + cx) * 8;
+    const bool act = c < d.C;
+    const int H = 2 * d.h, W = 2 * d.w;
+    const int64_t Mo = (int64_t)d.n_img * H * W;
+    float sc[8], sh[8], part[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; part[0][e] = 0.f; part[1][e] = 0.f; }
+    if (act && d.scale) { load8f(d.scale + c, sc); load8f(d.shift + c, sh); }
+    const float lo = d.relu ? 0.f : -3.0e38f;
+    if (act) {
+        for (int64_t m = (int64_t)blockIdx.y * RB + ry; m < Mo; m += (int64_t)gridDim.y * RB) {
+            const int n = (int)(m / ((int64_t)H * W));
+            const int rem = (int)(m - (int64_t)n * H * W);
+            const int Y = rem / W, X = rem - Y * W;
+            int y0, y1, x0, x1;
+            float ly, lx;
+            src2(Y, d.h, y0, y1, ly);
+            src2(X, d.w, x0, x1, lx);
+            const int64_t b = (int64_t)n * d.h * d.w;
+            float a[8], bq[8], cq[8], dq[8], o[8];
+            ld8<F32>(d.x, (b + (int64_t)y0 * d.w + x0) * d.ldx + c, a);
+            ld8<F32>(d.x, (b + (int64_t)y0 * d.w + x1) * d.ldx + c, bq);
+            ld8<F32>(d.x, (b + (int64_t)y1 * d.w + x0) * d.ldx + c, cq);
+            ld8<F32>(d.x, (b + (int64_t)y1 * d.w + x1) * d.ldx + c, dq);
+            const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = hy * (hx * a[e] + lx * bq[e]) + ly * (hx * cq[e] + lx * dq[e]);
+                o[e] = fmaxf(fmaf(v, sc[e], sh[e]), lo);
+            }
+            if (F32) {
+                store8f(reinterpret_cast<float*>(d.y) + m * d.ldy + c, o);
+            } else {
+                const uint4 ov = pack8(o);
+                *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(d.y) + m * d.ldy + c) = ov;
+                if (d.stat_acc) {
+                    float g[8];
+                    unpack8(ov, g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { part[0][e] += g[e]; part[1][e] += g[e] * g[e]; }
+                }
+            }
+        }
+    }
+    if (!F32 && d.stat_acc) block_colsum<CGB, 2>(part, red, d.stat_acc, d.C, blockIdx.x * CGB, 2 * d.C, blockIdx.y % DS_R);
+}
+
+// adjoint: a low-resolution pixel (y, x) is read by output rows 2y-1 .. 2y+2 (weights 0.25, 0.75, 0.75, 0.25), plus,
+// at the borders, the clamped reads: row 0 also takes the weight that would have gone to row -1 and row h-1 the
+// one for row h.  Implemented as a gather over the <= 4x4 outputs with the weight each gives to (y, x).
+template <int CGB>
+__global__ __launch_bounds__(256) void up2_bwd_kernel(const dsaspp_up2_desc d) {
+    __shared__ float red[256 * 16];
+    constexpr int RB = 256 / CGB;
+    const int cx = threadIdx.x % CGB, ry = threadIdx.x / CGB;
+    const int c = (blockIdx.x * CGB + cx) * 8;
+    const bool act = c < d.C;
+    const int H = 2 * d.h, W = 2 * d.w;
+    const int64_t Mi = (int64_t)d.n_img * d.h * d.w;
+    float mu[8], rs[8], part[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { mu[e] = 0.f; rs[e] = 1.f; part[0][e] = 0.f; part[1][e] = 0.f; }
+    if (act && d.s_acc) { load8f(d.mean + c, mu); load8f(d.rstd + c, rs); }
+    const u16* dyg = reinterpret_cast<const u16*>(d.y);
+    if (act) {
+        for (int64_t m = (int64_t)blockIdx.y * RB + ry; m < Mi; m += (int64_t)gridDim.y * RB) {
+            const int n = (int)(m / ((int64_t)d.h * d.w));
+            const int rem = (int)(m - (int64_t)n * d.h * d.w);
+            const int yl = rem / d.w, xl = rem - yl * d.w;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            const int Y0 = max(2 * yl - 1, 0), Y1 = min(2 * yl + 2, H - 1);
+            const int X0 = max(2 * xl - 1, 0), X1 = min(2 * xl + 2, W - 1);
+            for (int Y = Y0; Y <= Y1; ++Y) {
+                int y0, y1;
+                float ly;
+                src2(Y, d.h, y0, y1, ly);
+                float wy = 0.f;
+                if (y0 == yl) wy += 1.f - ly;
+                if (y1 == yl) wy += ly;
+                if (wy == 0.f) continue;
+                for (int X = X0; X <= X1; ++X) {
+                    int x0, x1;
+                    float lx;
+                    src2(X, d.w, x0, x1, lx);
+                    float wx = 0.f;
+                    if (x0 == xl) wx += 1.f - lx;
+                    if (x1 == xl) wx += lx;
+                    if (wx == 0.f) continue;
+                    float g[8];
+                    unpack8(*reinterpret_cast<const uint4*>(dyg + (((int64_t)n * H + Y) * W + X) * d.ldy + c), g);
+                    const float wgt = wy * wx;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(wgt, g[e], acc[e]);
+                }
+            }
+            if (d.dx_f32) store8f(reinterpret_cast<float*>(d.dx) + m * d.lddx + c, acc);
+            else *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(d.dx) + m * d.lddx + c) = pack8(acc);
+            if (d.s_acc) {
+                float yv[8];
+                unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(d.x) + m * d.ldx + c), yv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    part[0][e] += acc[e];
+                    part[1][e] += acc[e] * ((yv[e] - mu[e]) * rs[e]);
+                }
+            }
+        }
+    }
+    if (d.s_acc) block_colsum<CGB, 2>(part, red, d.s_acc, d.C, blockIdx.x * CGB, 2 * d.C, blockIdx.y % DS_R);
+}
+
+dim3 up2_grid(int C, int64_t M, int cgb) {
+    const int gx = ((C + 7) / 8 + cgb - 1) / cgb;
+    const int rb = 256 / cgb;
+    int64_t gy = (M + rb - 1) / rb;
+    const int64_t cap = (4096 + gx - 1) / gx;
+    if (gy > cap) gy = cap;
+    if (gy < 1) gy = 1;
+    return dim3(gx, (unsigned)gy);
+}
+
+int up2_check(const dsaspp_up2_desc* d, const char* who) {
+    DS_REQUIRE(d && d->n_img > 0 && d->h > 0 && d->w > 0 && d->C > 0 && d->C % 8 == 0, "%s: bad geometry", who);
+    DS_REQUIRE(d->y && d->ldy % 8 == 0 && d->ldy >= d->C, "%s: bad high-resolution tensor", who);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int dsaspp_upsample2_fwd(const dsaspp_up2_desc* d, dsaspp_stream_t stream) {
+    if (int rc = up2_check(d, "upsample2_fwd")) return rc;
+    DS_REQUIRE(d->x && d->ldx % 8 == 0 && d->ldx >= d->C, "upsample2_fwd: bad input");
+    DS_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), "upsample2_fwd: scale/shift must come together");
+    DS_REQUIRE(d->dtype == 0 || (d->dtype == 1 && !d->stat_acc), "upsample2_fwd: the fp32 form has no statistics");
+    const int64_t Mo = (int64_t)d->n_img * 4 * d->h * d->w;
+    const int cgb = d->C <= 64 ? 8 : 32;
+    const dim3 grid = up2_grid(d->C, Mo, cgb);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == 1) {
+        if (cgb == 8) hipLaunchKernelGGL((up2_fwd_kernel<8, true>), grid, dim3(256), 0, s, *d);
+        else hipLaunchKernelGGL((up2_fwd_kernel<32, true>), grid, dim3(256), 0, s, *d);
+    } else {
+        if (cgb == 8) hipLaunchKernelGGL((up2_fwd_kernel<8, false>), grid, dim3(256), 0, s, *d);
+        else hipLaunchKernelGGL((up2_fwd_kernel<32, false>), grid, dim3(256), 0, s, *d);
+    }
+    DS_LAUNCH_CHECK("upsample2_fwd");
+    return 0;
+}
+
+extern "C" int dsaspp_upsample2_bwd(const dsaspp_up2_desc* d, dsaspp_stream_t stream) {
+    if (int rc = up2_check(d, "upsample2_bwd")) return rc;
+    DS_REQUIRE(d->dx && d->lddx % 8 == 0 && d->lddx >= d->C, "upsample2_bwd: bad output");
+    if (d->s_acc) DS_REQUIRE(d->x && d->ldx % 8 == 0 && d->mean && d->rstd, "upsample2_bwd: s_acc needs yref (x), mean and rstd");
+    const int64_t Mi = (int64_t)d->n_img * d->h * d->w;
+    const int cgb = d->C <= 64 ? 8 : 32;
+    const dim3 grid = up2_grid(d->C, Mi, cgb);
+    if (cgb == 8) hipLaunchKernelGGL(up2_bwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL(up2_bwd_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, *d);
+    DS_LAUNCH_CHECK("upsample2_bwd");
+    return 0;
+}

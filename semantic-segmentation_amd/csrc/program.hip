@@ -37,6 +37,7 @@ union AnyDesc {
     dsaspp_generic_desc gen;
     dsaspp_stem3_desc stem3;
     dsaspp_dw_desc dw;
+    dsaspp_up2_desc up2;
 };
 struct Op {
     int32_t kind;
@@ -71,6 +72,8 @@ size_t desc_size(int32_t op) {
         case DSASPP_OP_COPY2D_BF16: return sizeof(dsaspp_generic_desc);
         case DSASPP_OP_STEM3: return sizeof(dsaspp_stem3_desc);
         case DSASPP_OP_DWCONV: return sizeof(dsaspp_dw_desc);
+        case DSASPP_OP_UP2_FWD:
+        case DSASPP_OP_UP2_BWD: return sizeof(dsaspp_up2_desc);
         default: return 0;
     }
 }
@@ -183,6 +186,8 @@ extern "C" int dsaspp_program_run(dsaspp_program* p, int32_t first, int32_t last
                 break;
             case DSASPP_OP_STEM3: rc = dsaspp_stem3x3s2(&o.d.stem3, s); break;
             case DSASPP_OP_DWCONV: rc = dsaspp_dwconv3x3(&o.d.dw, s); break;
+            case DSASPP_OP_UP2_FWD: rc = dsaspp_upsample2_fwd(&o.d.up2, s); break;
+            case DSASPP_OP_UP2_BWD: rc = dsaspp_upsample2_bwd(&o.d.up2, s); break;
             default: rc = dsaspp_set_error("program_run: unknown op %d at %d", o.kind, i);
         }
         if (timed) {

@@ -128,6 +128,8 @@ class DenseASPP(nn.Module):
             self.features.add_module('transition%d' % blk.index, tr)
         if sp.kind != 'mobilenet':
             self.features.add_module('norm5', nn.BatchNorm2d(sp.c_feat))
+            if sp.output_stride == 16:
+                self.features.add_module('upsample', nn.Upsample(scale_factor=2, mode='bilinear'))
         for a in sp.aspp:
             setattr(self, a.prefix, _holder_aspp(a.cin, a.d0, a.d1, a.rate, a.bn_start))
         self.classification = nn.Sequential(

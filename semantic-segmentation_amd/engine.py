@@ -74,8 +74,9 @@ class Slab:
 
 class Engine:
     def __init__(self, model, batch, height, width, training, backend, device):
-        if height % 8 or width % 8:
-            raise ValueError('input height and width must be multiples of 8 (got %dx%d)' % (height, width))
+        mult = getattr(model.spec, 'output_stride', 8)
+        if height % mult or width % mult:
+            raise ValueError('input height and width must be multiples of %d (got %dx%d)' % (mult, height, width))
         self.model = model
         self.spec = model.spec
         self.arena = model.arena
@@ -106,6 +107,10 @@ class Engine:
         self.H1, self.W1 = height // 4, width // 4          # block 1
         self.H2, self.W2 = height // 8, width // 8          # blocks 2-4, ASPP
         self.M0, self.M1, self.M2 = B * self.H0 * self.W0, B * self.H1 * self.W1, B * self.H2 * self.W2
+        self.os16 = getattr(sp, 'output_stride', 8) == 16
+        self.H3, self.W3 = height // 16, width // 16        # blocks 3-4 at output stride 16
+        self.M3 = B * self.H3 * self.W3
+        self.geo = {4: (self.M1, self.H1, self.W1), 8: (self.M2, self.H2, self.W2), 16: (self.M3, self.H3, self.W3)}
 
         # ---- activations
         self.mobilenet = sp.kind == 'mobilenet'
@@ -122,15 +127,17 @@ class Engine:
             self.col = zeros(self.M0 * S.STEM_KPAD, bf16)
             self.c0out = zeros(self.M0 * sp.c_stem, bf16)
             for blk in sp.blocks:
-                M, H, W = (self.M1, self.H1, self.W1) if blk.index == 1 else (self.M2, self.H2, self.W2)
+                M, H, W = self.geo[blk.res]
                 self.slabs.append(Slab(self, M, blk.C, H, W, training))
-            self.t1tmp = zeros(self.M1 * sp.blocks[0].cout, bf16)
-            self.t4out = zeros(self.M2 * sp.c_feat, bf16)
+            # un-pooled output of a transition that is followed by 2x2 average pooling
+            self.t1tmp = zeros(max(self.geo[b.res][0] * b.cout for b in sp.blocks if b.pool_after), bf16)
+            self.Mf = self.geo[sp.blocks[-1].res][0]           # pixels of the trunk output (norm5 input)
+            self.t4out = zeros(self.Mf * sp.c_feat, bf16)
         # bottleneck tensors: kept per layer when training (needed by backward), shared otherwise
         self.y1 = {}
         shared = {}
         for blk in sp.blocks:
-            M = self.M1 if blk.index == 1 else self.M2
+            M = self.geo[blk.res][0]
             for l in blk.layers:
                 if training:
                     self.y1[l.prefix] = zeros(M * l.mid, bf16)
@@ -207,8 +214,8 @@ class Engine:
             self.dlogits16 = zeros(self.M2 * S.CLS_PAD, bf16)
             self.argmax0 = torch.zeros(self.M1 * sp.c_stem, dtype=torch.uint8, device=dev)
             cmax_mid = max([l.mid for b in sp.blocks for l in b.layers] + [sp.d0])
-            big = max(self.M0 * sp.c_stem, self.M2 * sp.c_feat, self.M1 * sp.blocks[0].cout,
-                      self.M1 * cmax_mid, self.M2 * cmax_mid)
+            big = max(self.M0 * sp.c_stem, self.M2 * sp.c_feat, self.M1 * cmax_mid, self.M2 * cmax_mid,
+                      *[self.geo[b.res][0] * b.cout for b in sp.blocks])
             self.tmp_a = zeros(big, bf16)
             # input of the BatchNorm backward (see bn_bwd_apply): bf16 like every other activation gradient, or fp32
             self.dr_f32 = int(getattr(model, 'bn_grad_dtype', torch.bfloat16) == torch.float32 or bf16 != torch.bfloat16)
@@ -381,10 +388,18 @@ class Engine:
         # ---- norm5 + ReLU into the ASPP slab; statistics of the result for the ASPP norm1 layers
         cf, A = sp.c_feat, self.aslab
         self._bn_finalize(ops, 'features.norm5', cf, acc=_r(self.acc[pending[0]]) if tr else None, acc_c0=0,
-                          acc_cn=cf if tr else 0, count=self.M2)
-        ops.op('bn_act', M=self.M2, C=cf, x=_r(self.t4out), ldx=cf, scale=self.bnt('features.norm5', 'scale', cf),
-               shift=self.bnt('features.norm5', 'shift', cf), relu=1, y=_r(A.x, sp.off_feat), ldy=A.C,
-               stat_acc=_r(self.acc['feat']) if tr else None)
+                          acc_cn=cf if tr else 0, count=self.Mf)
+        if self.os16:
+            # output stride 16: norm5 -> bilinear x2 -> (ReLU heading ASPP_3); the affine map commutes with the
+            # interpolation, so one kernel reads the raw 1/16 map and writes ReLU(norm5) at 1/8 into the ASPP slab
+            ops.op('up2_fwd', n_img=B, h=self.H3, w=self.W3, C=cf, x=_r(self.t4out), ldx=cf,
+                   scale=self.bnt('features.norm5', 'scale', cf), shift=self.bnt('features.norm5', 'shift', cf), relu=1,
+                   y=_r(A.x, sp.off_feat), ldy=A.C, stat_acc=_r(self.acc['feat']) if tr else None, dx=None, lddx=0, dx_f32=0,
+                   mean=None, rstd=None, s_acc=None, dtype=self.dtype_code)
+        else:
+            ops.op('bn_act', M=self.M2, C=cf, x=_r(self.t4out), ldx=cf, scale=self.bnt('features.norm5', 'scale', cf),
+                   shift=self.bnt('features.norm5', 'shift', cf), relu=1, y=_r(A.x, sp.off_feat), ldy=A.C,
+                   stat_acc=_r(self.acc['feat']) if tr else None)
         if tr:
             # statistics of the feature channels, shared by every later ASPP norm1
             ops.op('bn_finalize', C=cf, acc=_r(self.acc['feat']), acc_c0=0, acc_cn=cf, count=float(self.M2),
@@ -593,11 +608,19 @@ class Engine:
         # ---- ReLU + norm5
         cf = sp.c_feat
         n5 = 'features.norm5'
-        slab_extract(A, sp.off_feat, cf, dr, relu=1, yref=_r(self.t4out), ldyref=cf, r_scale=self.bnt(n5, 'scale', cf),
-                     r_shift=self.bnt(n5, 'shift', cf), r_mean=self.bnt(n5, 'mean', cf), r_rstd=self.bnt(n5, 'rstd', cf),
-                     s_acc=_r(self.acc['features.norm5.s']), dz_f32=self.dr_f32)
-        bn_bwd(n5, cf, 'features.norm5.s', M, 0)
-        bn_apply(cf, M, dr, self.t4out, dz)
+        if self.os16:
+            # ReLU mask from the stored (post-ReLU) slab values, then the adjoint of the x2 upsample with the
+            # BatchNorm-backward sums of norm5 taken at 1/16 resolution
+            slab_extract(A, sp.off_feat, cf, dy1, relu=1, yref=_r(A.x, sp.off_feat), ldyref=A.C)
+            ops.op('up2_bwd', n_img=B, h=self.H3, w=self.W3, C=cf, x=_r(self.t4out), ldx=cf, scale=None, shift=None, relu=0,
+                   y=_r(dy1), ldy=cf, stat_acc=None, dx=_r(dr), lddx=cf, dx_f32=self.dr_f32, mean=self.bnt(n5, 'mean', cf),
+                   rstd=self.bnt(n5, 'rstd', cf), s_acc=_r(self.acc['features.norm5.s']), dtype=0)
+        else:
+            slab_extract(A, sp.off_feat, cf, dr, relu=1, yref=_r(self.t4out), ldyref=cf, r_scale=self.bnt(n5, 'scale', cf),
+                         r_shift=self.bnt(n5, 'shift', cf), r_mean=self.bnt(n5, 'mean', cf), r_rstd=self.bnt(n5, 'rstd', cf),
+                         s_acc=_r(self.acc['features.norm5.s']), dz_f32=self.dr_f32)
+        bn_bwd(n5, cf, 'features.norm5.s', self.Mf, 0)
+        bn_apply(cf, self.Mf, dr, self.t4out, dz)
         dz_cur = dz            # gradient w.r.t. the output of the last transition conv, [M2][cout]
 
         # ---- transitions and dense blocks, last to first

@@ -18,8 +18,9 @@ class DenseLayerSpec:
 
 
 class BlockSpec:
-    def __init__(self, index, c0, layers, dil, pool_after):
+    def __init__(self, index, c0, layers, dil, pool_after, res=8):
         self.index, self.c0, self.layers, self.dil, self.pool_after = index, c0, layers, dil, pool_after
+        self.res = res          # the block runs at 1/res of the input resolution
         self.C = c0 + sum(l.growth for l in layers)
         self.trans_prefix = 'features.transition%d' % index
         self.cout = self.C // 2
@@ -76,21 +77,24 @@ class NetSpec:
         self.dropout0, self.dropout1 = cfg['dropout0'], cfg['dropout1']
 
     def __init__(self, cfg, n_class=19, output_stride=8):
-        if int(output_stride) != 8:
-            raise NotImplementedError('the MI355X path implements output_stride=8 (got %r)' % (output_stride,))
+        if int(output_stride) not in (8, 16):
+            raise ValueError('output_stride must be 8 or 16 (got %r)' % (output_stride,))
         self.cfg = dict(cfg)
         self.n_class = n_class
+        self.output_stride = int(output_stride)
+        fs = self.output_stride // 8          # 2: transition2 pools, blocks 3-4 run at 1/16 and norm5 is followed by a x2 upsample
         g, bn = cfg['growth_rate'], cfg['bn_size']
         if cfg.get('drop_rate', 0):
             raise NotImplementedError('dense-layer drop_rate > 0 is not implemented (all reference cfgs use 0)')
         c = cfg['num_init_features']
         self.c_stem = c
-        dil = (1, 1, 2, 4)
+        dil = (1, 1, 2 // fs, 4 // fs)
+        res = (4, 8, 8 * fs, 8 * fs)
         self.blocks = []
         for b, n in enumerate(cfg['block_config']):
             layers = [DenseLayerSpec('features.denseblock%d.denselayer%d' % (b + 1, i + 1), c + i * g, bn * g, g, dil[b])
                       for i in range(n)]
-            blk = BlockSpec(b + 1, c, layers, dil[b], pool_after=(b == 0))
+            blk = BlockSpec(b + 1, c, layers, dil[b], pool_after=(b == 0 or (b == 1 and fs == 2)), res=res[b])
             self.blocks.append(blk)
             c = blk.cout
         self._head(cfg, c)
@@ -101,13 +105,12 @@ class NetSpec:
 
     def conv_macs(self, height, width):
         macs = (height // 2) * (width // 2) * STEM_K * self.c_stem
-        px = (height // 4) * (width // 4)
         for blk in self.blocks:
+            px = (height // blk.res) * (width // blk.res)
             for l in blk.layers:
                 macs += px * l.cin * l.mid + px * l.mid * 9 * l.growth
             macs += px * blk.C * blk.cout
-            if blk.pool_after:
-                px //= 4
+        px = (height // 8) * (width // 8)
         for a in self.aspp:
             macs += px * a.cin * a.d0 + px * a.d0 * 9 * a.d1
         macs += px * self.C_aspp * self.n_class

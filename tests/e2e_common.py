@@ -7,9 +7,9 @@ from conftest import TINY_CFG  # noqa: F401
 from oracle.dense_aspp_ref import DenseASPPRef, make_dropout_masks
 
 
-def make_pair(cfg, seed=0, randomize_bn=True):
+def make_pair(cfg, seed=0, randomize_bn=True, output_stride=8):
     torch.manual_seed(seed)
-    ref = DenseASPPRef(cfg)
+    ref = DenseASPPRef(cfg, output_stride=output_stride)
     if randomize_bn:
         for m in ref.modules():
             if isinstance(m, torch.nn.BatchNorm2d):
@@ -17,7 +17,7 @@ def make_pair(cfg, seed=0, randomize_bn=True):
                 m.bias.data.uniform_(-0.3, 0.3)
                 m.running_mean.uniform_(-0.2, 0.2)
                 m.running_var.uniform_(0.5, 1.5)
-    mod = denseASPP.DenseASPP(cfg)
+    mod = denseASPP.DenseASPP(cfg, 19, output_stride)
     mod.load_state_dict(ref.state_dict())
     return ref, mod
 

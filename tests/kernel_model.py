@@ -306,6 +306,38 @@ def op_dwconv(f):
     _view(f['y'], y.shape[0], C, f['ldy']).copy_(y.to(bf16))
 
 
+def op_up2_fwd(f):
+    n, h, w, C = f['n_img'], f['h'], f['w'], f['C']
+    x = _view(f['x'], n * h * w, C, f['ldx']).to(torch.float32).view(n, h, w, C).permute(0, 3, 1, 2)
+    v = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False).permute(0, 2, 3, 1).reshape(-1, C)
+    if f['scale'] is not None:
+        v = v * _vec(f['scale'], C) + _vec(f['shift'], C)
+    if f['relu']:
+        v = v.clamp_min(0)
+    _view(f['y'], v.shape[0], C, f['ldy']).copy_(v.to(bf16))
+    if f['stat_acc'] is not None:
+        s = _rbf(v)
+        st = _view(f['stat_acc'], R, 2 * C, 2 * C)
+        st[0, :C] += s.sum(0)
+        st[0, C:] += (s * s).sum(0)
+
+
+def op_up2_bwd(f):
+    n, h, w, C = f['n_img'], f['h'], f['w'], f['C']
+    dy = _view(f['y'], n * 4 * h * w, C, f['ldy']).to(torch.float32).view(n, 2 * h, 2 * w, C).permute(0, 3, 1, 2)
+    with torch.enable_grad():
+        x0 = torch.zeros(n, C, h, w, requires_grad=True)
+        F.interpolate(x0, scale_factor=2, mode='bilinear', align_corners=False).backward(dy)
+    dx = x0.grad.permute(0, 2, 3, 1).reshape(-1, C)
+    _view(f['dx'], n * h * w, C, f['lddx']).copy_(dx if f['dx_f32'] else dx.to(bf16))
+    if f['s_acc'] is not None:
+        yv = _view(f['x'], n * h * w, C, f['ldx']).to(torch.float32)
+        xh = (yv - _vec(f['mean'], C)) * _vec(f['rstd'], C)
+        acc = _view(f['s_acc'], R, 2 * C, 2 * C)
+        acc[0, :C] += dx.sum(0)
+        acc[0, C:] += (dx * xh).sum(0)
+
+
 def op_maxpool_fwd(f):
     n, H, W, C = f['n_img'], f['H'], f['W'], f['C']
     x = _view(f['x'], n * H * W, C, f['ldx']).to(torch.float32)
@@ -432,7 +464,7 @@ OPS = {
     'avgpool_fwd': op_avgpool_fwd, 'avgpool_bwd': op_avgpool_bwd, 'im2col': op_im2col,
     'maxpool_fwd': op_maxpool_fwd, 'maxpool_bwd': op_maxpool_bwd, 'upce': op_upce, 'ce_finalize': op_ce_finalize,
     'up_fwd': op_up_fwd, 'up_bwd': op_up_bwd, 'up_argmax': op_up_argmax, 'memset': op_memset, 'copy2d': op_copy2d,
-    'stem3': op_stem3, 'dwconv': op_dwconv,
+    'stem3': op_stem3, 'dwconv': op_dwconv, 'up2_fwd': op_up2_fwd, 'up2_bwd': op_up2_bwd,
 }
 
 

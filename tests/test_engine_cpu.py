@@ -125,7 +125,35 @@ def test_ctor_forms():
     b = denseASPP.DenseASPP(object(), model_cfg=TINY_CFG)
     c = denseASPP.DenseASPP(TINY_CFG, n_class=7)
     assert a.spec.n_class == b.spec.n_class == 19 and c.spec.n_class == 7
-    with pytest.raises(NotImplementedError):
-        denseASPP.DenseASPP(TINY_CFG, output_stride=16)
+    assert denseASPP.DenseASPP(TINY_CFG, output_stride=16).spec.output_stride == 16
+    with pytest.raises(ValueError):
+        denseASPP.DenseASPP(TINY_CFG, output_stride=32)
     with pytest.raises(TypeError):
         denseASPP.DenseASPP()
+
+
+def test_output_stride_16_fp32(fp32_model):
+    """DenseASPP(model_cfg, n_class, output_stride=16): transition2 pools, blocks 3-4 run at 1/16 with halved
+    dilations and norm5 is followed by a bilinear x2 upsample; forward, loss, every gradient and the running
+    statistics reproduce the oracle."""
+    ref, mod = make_pair(TINY_CFG, output_stride=16)
+    mod.set_backend(kernel_model.ModelBackend())
+    assert list(ref.state_dict().keys()) == list(mod.state_dict().keys())
+    x, labels = make_batch(2, 64, 96)
+    ref.eval(); mod.eval()
+    with torch.no_grad():
+        yr, ym = ref(x), mod(x)
+    assert ym.shape == yr.shape == (2, 19, 64, 96)
+    assert float((yr - ym).abs().max() / yr.abs().max()) < 1e-4
+    masks = make_dropout_masks(ref, 2, torch.Generator().manual_seed(5))
+    loss_r, g_ref = oracle_train(ref, x, labels, masks)
+    mod.train()
+    loss_m = mod.train_step(x, labels, dropout_masks=masks)
+    assert abs(float(loss_r) - float(loss_m)) < 1e-5
+    rel, cos, worst = grad_report(g_ref, {n: p.grad for n, p in mod.named_parameters()})
+    assert rel < 1e-3 and cos > 0.99999, (rel, cos, worst)
+    br = dict(ref.named_buffers())
+    for n, b in mod.named_buffers():
+        assert float((br[n].float() - b.float()).abs().max()) < 1e-4, n
+    with pytest.raises(ValueError):
+        mod.eval()(torch.zeros(1, 3, 72, 96))          # 72 is a multiple of 8 but not of 16

@@ -76,8 +76,9 @@ def _copy_engine_state(src, dst):
         cp(getattr(src, k), getattr(dst, k))
 
 
-def test_train_step_tiny():
-    ref, mod = make_pair(TINY_CFG)
+@pytest.mark.parametrize('output_stride', [8, 16])
+def test_train_step_tiny(output_stride):
+    ref, mod = make_pair(TINY_CFG, output_stride=output_stride)
     cpu_mod = copy.deepcopy(mod)
     cpu_mod.set_backend(kernel_model.ModelBackend())
     x, labels = make_batch(2, 64, 96)
