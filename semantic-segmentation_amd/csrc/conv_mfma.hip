@@ -68,8 +68,15 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8 && BP < 256) ? 4 : 2) v
     const int H = d.H, W = d.W, cin = d.cin, cout = d.cout, taps = d.taps, dil = d.dil;
     const int hw = H * W;
     const int Ktot = taps * cin;
+    // Merged-K form of a 3x3 convolution with fewer input channels than one K-step (the data gradient of a dense
+    // layer's 3x3: 48 or 32 channels): stepping tap by tap would leave a quarter or half of every 64-wide K-step
+    // empty, so the nine taps are laid end to end (K = 9*cin, exactly how the weights are stored) and every 16-byte
+    // chunk of a K-step finds its own tap: 7 instead of 9 steps for 48 channels, 5 instead of 9 for 32.
+    const bool merged = (PRO == 0) && taps == 9 && cin < BK;
+    const int cpt = cin >> 3;                          // chunks per tap
     const int csteps = (cin + BK - 1) / BK;
-    const int ksteps = taps * csteps;
+    const int ksteps = merged ? (Ktot + BK - 1) / BK : taps * csteps;
+    const int cinW = merged ? Ktot : cin;              // the weight cursor sees a 1x1 convolution over K = 9*cin
     const bool has_scale = d.in_scale != nullptr;
 
     if (PRO != 0 && has_scale) {
@@ -146,6 +153,22 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8 && BP < 256) ? 4 : 2) v
 
     // Activation chunks travel through registers (the prologue is applied on their way to LDS), PD K-steps ahead.
     constexpr int PD = BIG ? 2 : 1;
+    const u16* a_ctr[AR];               // merged-K form: the row's own pixel, and which of its nine taps are inside the image
+    unsigned a_tapok[AR];
+    if (merged) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            a_ctr[i] = xg + (((int64_t)a_n[i] * H + a_h[i]) * W + a_w[i]) * d.ldx;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int hh = a_h[i] + (t / 3 - 1) * dil, ww = a_w[i] + (t % 3 - 1) * dil;
+                if (a_ok[i] && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) mk |= 1u << t;
+            }
+            a_tapok[i] = mk;
+        }
+    }
+    int kstep_a = 0;                    // merged-K form: index of the next K-step the activation cursor loads
     uint4 areg[PD][AR], wreg[WR];
     bool lval[PD][AR], wval[WR];        // validity of the chunks held in areg / wreg
     int lc[PD];                         // channel of the chunks held in areg (for the prologue tables)
@@ -153,6 +176,22 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8 && BP < 256) ? 4 : 2) v
     int tapw = 0, c0w = 0;              // weight cursor
 
     auto loadA = [&](const int st) {
+        if (merged) {
+            const int kc = kstep_a * 8 + ck;               // chunk index along K = (tap, 8-channel group)
+            const int tp = kc / cpt, c8 = kc - tp * cpt;
+            const bool kvalid = tp < 9;
+            const int ty = tp / 3, tx = tp - ty * 3;
+            const int64_t toff = (int64_t)((ty - 1) * W + (tx - 1)) * dil * d.ldx + c8 * 8;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const bool ok = kvalid && ((a_tapok[i] >> tp) & 1u);
+                areg[st][i] = *reinterpret_cast<const uint4*>(a_ctr[i] + (ok ? toff : 0));   // always a mapped address
+                lval[st][i] = ok;
+            }
+            lc[st] = 0;
+            ++kstep_a;
+            return;
+        }
         const int c = c0 + ck * 8;
         const bool cvalid = c < cin;
         const int co = cvalid ? c : 0;
@@ -179,13 +218,13 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8 && BP < 256) ? 4 : 2) v
             for (int i = 0; i < WR; ++i) {
                 // K tail: the activation chunk is zeroed, so the weight chunk only has to be finite -> channel 0
                 const int cc = c0w + wd_chunk[i];
-                const int kq = cc < cin ? tapw * cin + cc : 0;
+                const int kq = cc < cinW ? tapw * cin + cc : 0;
                 __builtin_amdgcn_global_load_lds((glb_p)(w_ptr[i] + kq), (lds_p)(slot + (i * 8 + wave) * 1024), 16, 0, 0);
             }
             wbuf ^= 1;
         } else {
             const int c = c0w + ck * 8;
-            const bool cvalid = c < cin;
+            const bool cvalid = c < cinW;
             const int ko = cvalid ? tapw * cin + c : 0;
 #pragma unroll
             for (int i = 0; i < WR; ++i) {
@@ -196,7 +235,7 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8 && BP < 256) ? 4 : 2) v
             }
         }
         c0w += BK;
-        if (c0w >= cin) {
+        if (c0w >= cinW) {
             c0w = 0;
             ++tapw;
         }
@@ -271,8 +310,9 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8 && BP < 256) ? 4 : 2) v
 
     auto run_k = [&]() {
         tap = 0; c0 = 0; tapw = 0; c0w = 0;
+        kstep_a = 0;
         wbuf = 0;
-        tap_setup(0);
+        if (!merged) tap_setup(0);
         loadW();                                   // weights of step 0
         loadA(0);
         if (PD > 1 && ksteps > 1) loadA(1);

@@ -68,6 +68,11 @@ def check_conv(f, tol=2e-2):
 
 
 CONV_CASES = [
+    # merged-K form (3x3, raw input with fewer channels than one K-step): K = 9*cin laid end to end
+    dict(n=2, H=11, W=9, cin=32, cout=128, taps=9, dil=2, scale=False, relu=False, epi_relu=True, e_scale=True, s_acc=True),
+    dict(n=1, H=13, W=21, cin=56, cout=192, taps=9, dil=1, scale=False, relu=False, ldx=64, stats=True),
+    dict(n=3, H=8, W=8, cin=16, cout=48, taps=9, dil=3, scale=False, relu=False, bias=True, y_f32=True),
+    dict(n=1, H=10, W=12, cin=8, cout=32, taps=9, dil=6, scale=False, relu=False),
     dict(n=2, H=9, W=13, cin=144, cout=192, taps=1, dil=1, ldx=160, stats=True),
     dict(n=1, H=16, W=24, cin=192, cout=48, taps=9, dil=2, ldy=96, yoff=48, stats=True),
     dict(n=2, H=12, W=20, cin=64, cout=128, taps=9, dil=6, bias=True, out_mask=True, stats=True),
