@@ -484,6 +484,13 @@ int dsaspp_program_add(dsaspp_program* p, int32_t op, const void* desc, int64_t 
 int dsaspp_program_size(const dsaspp_program* p);
 /* run ops [first, last) ; last < 0 means to the end */
 int dsaspp_program_run(dsaspp_program* p, int32_t first, int32_t last, dsaspp_stream_t stream);
+/* Ops marked with side != 0 are enqueued on a second HIP stream that the program owns: before each of them the
+ * side stream waits for everything the run has enqueued on the caller's stream so far, and the caller's stream waits
+ * for the side stream at the end of every dsaspp_program_run call.  The recorder must make sure that nothing enqueued
+ * later in the same run overwrites what a side op reads or reads what it writes (the engine marks the dense-layer
+ * weight gradients, whose inputs live in per-layer buffers and whose outputs only the optimizer reads): two MFMA
+ * kernels that are each latency bound overlap to 1.17-1.23x of their sequential time. */
+int dsaspp_program_set_side(dsaspp_program* p, int32_t op_index, int32_t side);
 /* Per-kernel timing with HIP events on the launch stream (measurement only): ops given a
  * non-zero tag are bracketed by two events on every run until the timing is read.
  * dsaspp_program_read_timing synchronises the recorded events, adds the elapsed milliseconds

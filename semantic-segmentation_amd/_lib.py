@@ -161,6 +161,7 @@ def load():
     lib.dsaspp_program_size.argtypes = [ctypes.c_void_p]
     lib.dsaspp_program_run.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
     lib.dsaspp_program_set_tag.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
+    lib.dsaspp_program_set_side.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
     lib.dsaspp_program_read_timing.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_double),
                                                ctypes.POINTER(ctypes.c_int64)]
     _lib = lib

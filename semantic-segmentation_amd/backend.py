@@ -69,6 +69,8 @@ class HipBackend:
             code, struct, _ = _lib.OPS[kind]
             d = fill_desc(struct, fields)
             _lib.check(self.lib.dsaspp_program_add(h, code, ctypes.byref(d), ctypes.sizeof(d)))
+        for i in sorted(getattr(oplist, 'side', ())):
+            _lib.check(self.lib.dsaspp_program_set_side(h, i, 1))
         return prog
 
     def call(self, kind, stream=None, **fields):

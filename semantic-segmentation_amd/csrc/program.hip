@@ -42,6 +42,7 @@ union AnyDesc {
 struct Op {
     int32_t kind;
     int32_t tag;
+    int32_t side;
     AnyDesc d;
 };
 struct Stamp {
@@ -83,6 +84,10 @@ struct dsaspp_program {
     std::vector<Op> ops;
     std::vector<Stamp> stamps;
     bool any_tag = false;
+    bool any_side = false;
+    hipStream_t side = nullptr;       // created on first use, on the device current at that time
+    hipEvent_t fork = nullptr, join = nullptr;
+    int side_device = -1;
 };
 
 extern "C" dsaspp_program* dsaspp_program_create(void) { return new (std::nothrow) dsaspp_program(); }
@@ -92,7 +97,18 @@ extern "C" void dsaspp_program_destroy(dsaspp_program* p) {
         (void)hipEventDestroy(st.a);
         (void)hipEventDestroy(st.b);
     }
+    if (p->fork) (void)hipEventDestroy(p->fork);
+    if (p->join) (void)hipEventDestroy(p->join);
+    if (p->side) (void)hipStreamDestroy(p->side);
     delete p;
+}
+
+extern "C" int dsaspp_program_set_side(dsaspp_program* p, int32_t op_index, int32_t side) {
+    DS_REQUIRE(p && op_index >= 0 && op_index < (int)p->ops.size(), "program_set_side: bad arguments");
+    p->ops[op_index].side = side ? 1 : 0;
+    p->any_side = false;
+    for (auto& o : p->ops) p->any_side = p->any_side || o.side != 0;
+    return 0;
 }
 
 extern "C" int dsaspp_program_set_tag(dsaspp_program* p, int32_t op_index, int32_t tag) {
@@ -131,6 +147,7 @@ extern "C" int dsaspp_program_add(dsaspp_program* p, int32_t op, const void* des
     Op o;
     o.kind = op;
     o.tag = 0;
+    o.side = 0;
     memset(&o.d, 0, sizeof(o.d));
     memcpy(&o.d, desc, want);
     try {
@@ -146,11 +163,33 @@ extern "C" int dsaspp_program_run(dsaspp_program* p, int32_t first, int32_t last
     const int n = (int)p->ops.size();
     if (last < 0 || last > n) last = n;
     DS_REQUIRE(first >= 0 && first <= last, "program_run: bad range [%d, %d)", first, last);
+    const dsaspp_stream_t main_s = s;
+    bool side_used = false;
+    if (p->any_side) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return dsaspp_set_error("program_run: hipGetDevice failed");
+        if (p->side && p->side_device != dev) return dsaspp_set_error("program_run: the program's side stream belongs to device %d, current device is %d", p->side_device, dev);
+        if (!p->side) {
+            if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&p->join, hipEventDisableTiming) != hipSuccess)
+                return dsaspp_set_error("program_run: could not create the side stream");
+            p->side_device = dev;
+        }
+    }
     for (int i = first; i < last; ++i) {
         const Op& o = p->ops[i];
         int rc = 0;
         Stamp st;
         const bool timed = o.tag != 0;
+        s = main_s;
+        if (o.side && p->side) {
+            // the side op sees everything enqueued on the caller's stream so far
+            if (hipEventRecord(p->fork, (hipStream_t)main_s) != hipSuccess || hipStreamWaitEvent(p->side, p->fork, 0) != hipSuccess)
+                return dsaspp_set_error("program_run: fork to the side stream failed");
+            s = (dsaspp_stream_t)p->side;
+            side_used = true;
+        }
         if (timed) {
             st.tag = o.tag;
             if (hipEventCreate(&st.a) != hipSuccess || hipEventCreate(&st.b) != hipSuccess)
@@ -197,8 +236,17 @@ extern "C" int dsaspp_program_run(dsaspp_program* p, int32_t first, int32_t last
         if (rc != 0) {
             char tmp[400];
             snprintf(tmp, sizeof(tmp), "%s", g_err);
+            if (side_used) {
+                (void)hipEventRecord(p->join, p->side);
+                (void)hipStreamWaitEvent((hipStream_t)main_s, p->join, 0);
+            }
             return dsaspp_set_error("program op %d (kind %d): %s", i, o.kind, tmp);
         }
+    }
+    if (side_used) {
+        // the caller's stream continues only after the side work of this run
+        if (hipEventRecord(p->join, p->side) != hipSuccess || hipStreamWaitEvent((hipStream_t)main_s, p->join, 0) != hipSuccess)
+            return dsaspp_set_error("program_run: join of the side stream failed");
     }
     return 0;
 }

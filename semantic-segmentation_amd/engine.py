@@ -46,6 +46,10 @@ class OpList(list):
     def __init__(self, dtype_code=0):
         super().__init__()
         self.dtype_code = dtype_code
+        self.side = set()       # indices of ops that may run on the program's side stream (see dsaspp_program_set_side)
+
+    def mark_side(self):
+        self.side.add(len(self) - 1)
 
     def op(self, kind, **fields):
         if self.dtype_code and kind in _DTYPE_OPS:
@@ -224,6 +228,16 @@ class Engine:
             # bottleneck gradients of the layers whose slab data gradients are applied together
             self.dgrad_group = max(1, min(4, int(getattr(model, 'dgrad_group', 4))))
             self.dy1_bufs = [self.tmp_c] + [zeros(max(self.M1, self.M2) * cmax_mid, bf16) for _ in range(self.dgrad_group - 1)]
+            # Dense-layer weight gradients on the side stream: their gradient inputs must not be overwritten by the
+            # next layers while they wait, so every dense layer gets private buffers for them (288 GB of HBM)
+            self.side_wgrad = bool(getattr(model, 'side_wgrad', False)) and not self.mobilenet
+            self.dz_l, self.dy1_l = {}, {}
+            if self.side_wgrad:
+                for blk in sp.blocks:
+                    Mb = self.geo[blk.res][0]
+                    for l in blk.layers:
+                        self.dz_l[l.prefix] = zeros(Mb * l.growth, bf16)
+                        self.dy1_l[l.prefix] = zeros(Mb * l.mid, bf16)
             self.coef = zeros(3 * max(sp.c_feat, cmax_mid, sp.c_stem))
             self.dw0pad = zeros(sp.c_stem * S.STEM_KPAD)
             n_drop = 5 * sp.d1 + sp.C_aspp
@@ -660,15 +674,21 @@ class Engine:
                     grp = grp[:1]
                 gi += len(grp)
                 c_lo = grp[-1].cin
+                grp_dy1 = []
                 for k, l in enumerate(grp):
                     n1, n2 = l.prefix + '.norm1', l.prefix + '.norm2'
                     y1 = self.y1[l.prefix]
-                    dy1k = self.dy1_bufs[k]
-                    slab_extract(slab, l.cin, l.growth, dz)
+                    side = self.side_wgrad
+                    dy1k = self.dy1_l[l.prefix] if side else self.dy1_bufs[k]
+                    dz_k = self.dz_l[l.prefix] if side else self.tmp_a
+                    grp_dy1.append(dy1k)
+                    slab_extract(slab, l.cin, l.growth, dz_k)
                     WG(n_img=B, H=H, W=W, cin=l.mid, cout=l.growth, taps=9, dil=l.dil, x=_r(y1), ldx=l.mid,
-                       in_scale=self.bnt(n2, 'scale', l.mid), in_shift=self.bnt(n2, 'shift', l.mid), in_relu=1, dz=_r(dz),
+                       in_scale=self.bnt(n2, 'scale', l.mid), in_shift=self.bnt(n2, 'shift', l.mid), in_relu=1, dz=_r(dz_k),
                        lddz=l.growth, dw=self.PG(l.prefix + '.conv2.weight'))
-                    C(n_img=B, H=H, W=W, cin=l.growth, cout=l.mid, taps=9, dil=l.dil, x=_r(dz), ldx=l.growth,
+                    if side:
+                        ops.mark_side()
+                    C(n_img=B, H=H, W=W, cin=l.growth, cout=l.mid, taps=9, dil=l.dil, x=_r(dz_k), ldx=l.growth,
                       w=self.WT16(l.prefix + '.conv2.weight'), y=_r(dr), ldy=l.mid, y_f32=self.dr_f32, epi_relu=1, ref=_r(y1), ldref=l.mid,
                       e_scale=self.bnt(n2, 'scale', l.mid), e_shift=self.bnt(n2, 'shift', l.mid),
                       e_mean=self.bnt(n2, 'mean', l.mid), e_rstd=self.bnt(n2, 'rstd', l.mid),
@@ -678,6 +698,8 @@ class Engine:
                     WG(n_img=B, H=H, W=W, cin=l.cin, cout=l.mid, taps=1, dil=1, x=_r(slab.x), ldx=slab.C,
                        in_scale=self.bnt(n1, 'scale', l.cin), in_shift=self.bnt(n1, 'shift', l.cin), in_relu=1, dz=_r(dy1k),
                        lddz=l.mid, dw=self.PG(l.prefix + '.conv1.weight'))
+                    if side:
+                        ops.mark_side()
                     cn = l.cin - c_lo
                     if cn > 0:     # channels produced by the later-processed layers of this group
                         C(n_img=B, H=H, W=W, cin=l.mid, cout=cn, taps=1, dil=1, x=_r(dy1k), ldx=l.mid,
@@ -689,7 +711,7 @@ class Engine:
                 multi = dict(n_src=len(grp))
                 for k, l in enumerate(grp):
                     n1 = l.prefix + '.norm1'
-                    src = (_r(self.dy1_bufs[k]), self.WT16(l.prefix + '.conv1.weight'), self.bnt(n1, 'scale', l.cin),
+                    src = (_r(grp_dy1[k]), self.WT16(l.prefix + '.conv1.weight'), self.bnt(n1, 'scale', l.cin),
                            self.bnt(n1, 'shift', l.cin), _r(self.acc[l.prefix + '.s1']), l.cin)
                     names = ('x', 'w', 'e_scale', 'e_shift', 's_acc', 's_ld') if k == 0 else \
                         tuple(n + str(k) for n in ('x', 'w', 'es', 'eh', 'sa', 'sl'))

@@ -71,3 +71,25 @@ for name, (kind, f) in cases.items():
     us = e0.elapsed_time(e1)*1e3/a.iters
     fl = 2.0*M*f['cout']*f['taps']*f['cin']*max(1, f.get('n_src', 0))
     print('%-14s %9.1f us  %7.1f TFLOP/s' % (name, us, fl/us/1e6), flush=True)
+
+# ---- do two different kernels overlap when they run on two streams?  (python tools_conv_bench.py --only overlap)
+if a.only == 'overlap':
+    from semantic_segmentation_amd.engine import OpList
+    kind, f = cases['fwd1x1']; f = dict(f); f['stat_acc'] = None
+    pairs = {'fwd1x1': (kind, f), 'wgrad1x1': cases['wgrad1x1'], 'dgrad3x3': cases['dgrad3x3'], 'wgrad3x3': cases['wgrad3x3'],
+             'slab_multi4': cases['slab_multi4']}
+    progs = {}
+    for name, (kind, f) in pairs.items():
+        ops = OpList()
+        for _ in range(a.iters): ops.op(kind, **f)
+        progs[name] = be.compile(ops)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    def wall(fn):
+        fn(); torch.cuda.synchronize()
+        t = time.time(); fn(); torch.cuda.synchronize(); return (time.time() - t) * 1e6 / a.iters
+    for x, y in (('fwd1x1', 'wgrad1x1'), ('dgrad3x3', 'wgrad3x3'), ('slab_multi4', 'wgrad1x1')):
+        tx = wall(lambda: progs[x].run(stream=s1.cuda_stream)); ty = wall(lambda: progs[y].run(stream=s1.cuda_stream))
+        def both():
+            progs[x].run(stream=s1.cuda_stream); progs[y].run(stream=s2.cuda_stream)
+        tb = wall(both)
+        print('%-12s %7.1f us + %-10s %7.1f us = %7.1f sequential; two streams: %7.1f us (%.2fx)' % (x, tx, y, ty, tx + ty, tb, (tx + ty) / tb), flush=True)
