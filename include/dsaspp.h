@@ -74,7 +74,7 @@ typedef struct dsaspp_conv_desc {
     int32_t ldy;
     int32_t y_f32;
     float* stat_acc;          /* [R][2*cout] sum / sum of squares of the stored output, or NULL */
-    int32_t epi_relu;         /* mask by sign of the reference pre-activation */
+    int32_t epi_relu;         /* mask by the reference pre-activation: 1 = ReLU (pre > 0), 2 = ReLU6 (0 < pre < 6; single-source forms) */
     const void* ref;          /* bf16 [M][ldref] */
     int32_t ldref;
     const float* e_scale;     /* [cout] or NULL */
@@ -339,6 +339,37 @@ typedef struct dsaspp_dw_desc {
 } dsaspp_dw_desc;
 int dsaspp_dwconv3x3(const dsaspp_dw_desc* d, dsaspp_stream_t stream);
 
+/* Backward of the depthwise 3x3 convolution above (training of the MobileNetV2 trunk; the reference
+ * trains it through autograd: graph_seg_test.py:129 builds the model, train.py-style loops call
+ * loss.backward()).  Geometry, prologue and weights are those of the forward call.
+ *   bwd_data:  da[n][h][w][c] = sum_{ky,kx} w[c][ky*3+kx] * dy[n][ho][wo][c]  over the output pixels with
+ *              ho*stride + (ky-1)*dil == h, wo*stride + (kx-1)*dil == w;
+ *              dx = da where the prologue's activation passes gradient (pre = x*in_scale+in_shift;
+ *              in_relu 1: pre > 0, 2: 0 < pre < 6, 0: everywhere), else 0 -- the gradient w.r.t. the
+ *              producer's BatchNorm output; with s_acc the BatchNorm-backward sums of that BatchNorm,
+ *              sum(dx) and sum(dx * (x - e_mean) * e_rstd), go to replica rows [R][2*C].
+ *   wgrad:     dw[c][ky*3+kx] += sum_{n,ho,wo} dy[n][ho][wo][c] * a[n][ho*stride+(ky-1)*dil][wo*stride+(kx-1)*dil][c]
+ *              (a = the prologue output rounded to bf16, zero outside the image), fp32 [C][9]. */
+typedef struct dsaspp_dwbwd_desc {
+    int32_t n_img, H, W, C;   /* forward input geometry; C a multiple of 8 */
+    int32_t stride, dil;
+    const void* x; int32_t ldx;       /* forward raw input, bf16 */
+    const float* in_scale; const float* in_shift; int32_t in_relu;
+    const void* w;                    /* bf16 [C][9] (bwd_data) */
+    const void* dy; int32_t lddy;     /* gradient w.r.t. the forward output, bf16 [N*Ho*Wo][lddy] */
+    void* dx; int32_t lddx;           /* bwd_data result, bf16 or fp32 [N*H*W][lddx] */
+    int32_t dx_f32;
+    const float* e_mean; const float* e_rstd; float* s_acc;   /* optional BatchNorm-backward sums */
+    float* dw;                        /* wgrad result, accumulated */
+} dsaspp_dwbwd_desc;
+int dsaspp_dwconv3x3_bwd_data(const dsaspp_dwbwd_desc* d, dsaspp_stream_t stream);
+int dsaspp_dwconv3x3_wgrad(const dsaspp_dwbwd_desc* d, dsaspp_stream_t stream);
+
+/* 3x3/2 pad-1 im2col of the NCHW fp32 network input to bf16 rows [N*(H/2)*(W/2)][ldcol], K order
+ * (ky, kx, ci), columns >= 27 zero: the MobileNetV2 stem's weight gradient is then a 1x1
+ * dsaspp_conv_wgrad with cin = ldcol (uses dsaspp_im2col_desc; ldcol >= 32, a multiple of 8). */
+int dsaspp_stem3_im2col(const dsaspp_im2col_desc* d, dsaspp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Bilinear x8 upsample (align_corners=False) fused with softmax cross-entropy
  * (replaces nn.Upsample(scale_factor=8, mode='bilinear') + CrossEntropyLoss(ignore_index)
@@ -469,7 +500,7 @@ enum {
     DSASPP_OP_AVGPOOL_BWD, DSASPP_OP_IM2COL, DSASPP_OP_MAXPOOL_FWD, DSASPP_OP_MAXPOOL_BWD,
     DSASPP_OP_UPCE, DSASPP_OP_CE_FINALIZE, DSASPP_OP_UP_FWD, DSASPP_OP_UP_BWD, DSASPP_OP_UP_ARGMAX,
     DSASPP_OP_MEMSET, DSASPP_OP_COPY2D, DSASPP_OP_COPY2D_BF16, DSASPP_OP_STEM3, DSASPP_OP_DWCONV,
-    DSASPP_OP_UP2_FWD, DSASPP_OP_UP2_BWD
+    DSASPP_OP_UP2_FWD, DSASPP_OP_UP2_BWD, DSASPP_OP_DW_BWD_DATA, DSASPP_OP_DW_WGRAD, DSASPP_OP_STEM3_COL
 };
 dsaspp_program* dsaspp_program_create(void);
 void dsaspp_program_destroy(dsaspp_program* p);

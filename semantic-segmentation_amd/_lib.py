@@ -89,6 +89,7 @@ dw_desc = STRUCTS['dsaspp_dw_desc']
 conf_desc = STRUCTS['dsaspp_conf_desc']
 prep_desc = STRUCTS['dsaspp_prep_desc']
 up2_desc = STRUCTS['dsaspp_up2_desc']
+dwbwd_desc = STRUCTS['dsaspp_dwbwd_desc']
 
 # op name -> (program op code, descriptor struct, direct entry point)
 OPS = {
@@ -116,6 +117,9 @@ OPS = {
     'dwconv': (ENUMS['DSASPP_OP_DWCONV'], dw_desc, 'dsaspp_dwconv3x3'),
     'up2_fwd': (ENUMS['DSASPP_OP_UP2_FWD'], up2_desc, 'dsaspp_upsample2_fwd'),
     'up2_bwd': (ENUMS['DSASPP_OP_UP2_BWD'], up2_desc, 'dsaspp_upsample2_bwd'),
+    'dw_bwd_data': (ENUMS['DSASPP_OP_DW_BWD_DATA'], dwbwd_desc, 'dsaspp_dwconv3x3_bwd_data'),
+    'dw_wgrad': (ENUMS['DSASPP_OP_DW_WGRAD'], dwbwd_desc, 'dsaspp_dwconv3x3_wgrad'),
+    'stem3_col': (ENUMS['DSASPP_OP_STEM3_COL'], im2col_desc, 'dsaspp_stem3_im2col'),
     # direct calls only (not recordable in a program)
     'confusion': (None, conf_desc, 'dsaspp_upsample8_confusion'),
     'preprocess': (None, prep_desc, 'dsaspp_preprocess'),

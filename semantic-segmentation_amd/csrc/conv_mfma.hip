@@ -561,7 +561,7 @@ __global__ __launch_bounds__(64 * WP * WQ, (WP * WQ == 8 && BP < 256) ? 4 : 2) v
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float pre = d.e_scale ? fmaf(rf[e], epar[BQ + cl + e], epar[2 * BQ + cl + e]) : rf[e];
-                        if (!(pre > 0.f)) v[e] = 0.f;
+                        if (!(pre > 0.f) || (d.epi_relu == 2 && pre >= 6.f)) v[e] = 0.f;
                     }
                 }
                 if ((EPI == 1 || EPI == 2) && want_s) {

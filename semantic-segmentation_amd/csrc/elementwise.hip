@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void grad_extract_kernel(const dsaspp_gradx_de
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float pre = d.r_scale ? fmaf(y[e], rs[e], rh[e]) : y[e];
-                    if (!(pre > 0.f)) v[e] = 0.f;
+                    if (!(pre > 0.f) || (d.relu == 2 && pre >= 6.f)) v[e] = 0.f;
                 }
             }
             if (d.dz_f32) store8f(reinterpret_cast<float*>(d.dz) + m * d.lddz + c, v);

@@ -38,6 +38,7 @@ union AnyDesc {
     dsaspp_stem3_desc stem3;
     dsaspp_dw_desc dw;
     dsaspp_up2_desc up2;
+    dsaspp_dwbwd_desc dwb;
 };
 struct Op {
     int32_t kind;
@@ -75,6 +76,9 @@ size_t desc_size(int32_t op) {
         case DSASPP_OP_DWCONV: return sizeof(dsaspp_dw_desc);
         case DSASPP_OP_UP2_FWD:
         case DSASPP_OP_UP2_BWD: return sizeof(dsaspp_up2_desc);
+        case DSASPP_OP_DW_BWD_DATA:
+        case DSASPP_OP_DW_WGRAD: return sizeof(dsaspp_dwbwd_desc);
+        case DSASPP_OP_STEM3_COL: return sizeof(dsaspp_im2col_desc);
         default: return 0;
     }
 }
@@ -227,6 +231,9 @@ extern "C" int dsaspp_program_run(dsaspp_program* p, int32_t first, int32_t last
             case DSASPP_OP_DWCONV: rc = dsaspp_dwconv3x3(&o.d.dw, s); break;
             case DSASPP_OP_UP2_FWD: rc = dsaspp_upsample2_fwd(&o.d.up2, s); break;
             case DSASPP_OP_UP2_BWD: rc = dsaspp_upsample2_bwd(&o.d.up2, s); break;
+            case DSASPP_OP_DW_BWD_DATA: rc = dsaspp_dwconv3x3_bwd_data(&o.d.dwb, s); break;
+            case DSASPP_OP_DW_WGRAD: rc = dsaspp_dwconv3x3_wgrad(&o.d.dwb, s); break;
+            case DSASPP_OP_STEM3_COL: rc = dsaspp_stem3_im2col(&o.d.im2col, s); break;
             default: rc = dsaspp_set_error("program_run: unknown op %d at %d", o.kind, i);
         }
         if (timed) {

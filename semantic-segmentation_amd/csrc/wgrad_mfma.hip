@@ -177,6 +177,10 @@ __global__ __launch_bounds__(64 * WQ * WC * KG, (WQ * WC == 8) ? 4 : 2) void wgr
                     for (int e = 0; e < 8; ++e) f[e] *= mk[e];
                     v = pack8(f);
                 } else {
+                    if (d.in_relu == 2) {      // ReLU6: the ceiling in fp32 (6 is exact in bf16), the floor below
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = fminf(f[e], 6.f);
+                    }
                     v = relu_bf8(pack8(f), d.in_relu ? 0u : 0x80008000u);     // ReLU after the rounding (packed 16-bit max)
                 }
             }

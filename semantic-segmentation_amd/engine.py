@@ -118,15 +118,12 @@ class Engine:
 
         # ---- activations
         self.mobilenet = sp.kind == 'mobilenet'
-        if self.mobilenet and training:
-            raise NotImplementedError('MobileNetDenseASPP on the MI355X path is inference only: call eval() first '
-                                      '(the depthwise / inverted-residual backward is not built)')
         self.x_in = zeros(B * 3 * height * width)
         self.slabs = []
         self.aslab = Slab(self, self.M2, sp.C_aspp, self.H2, self.W2, training)
         self.logits = zeros(self.M2 * S.CLS_PAD)
         if self.mobilenet:
-            self._alloc_mobilenet(zeros, bf16)
+            self._alloc_mobilenet(zeros, bf16, training)
         else:
             self.col = zeros(self.M0 * S.STEM_KPAD, bf16)
             self.c0out = zeros(self.M0 * sp.c_stem, bf16)
@@ -171,11 +168,14 @@ class Engine:
             self.acc[name] = zeros(self.R * 2 * C)
 
         if self.mobilenet:
-            bn_tables(sp.stem_prefix + '.1', sp.c_stem)
+            bn_list = [(sp.stem_prefix + '.1', sp.c_stem)]
             for b in sp.ir:
-                bn_tables(b.prefix + '.conv.1', b.hid)
-                bn_tables(b.prefix + '.conv.4', b.hid)
-                bn_tables(b.prefix + '.conv.7', b.cout)
+                bn_list += [(b.prefix + '.conv.1', b.hid), (b.prefix + '.conv.4', b.hid), (b.prefix + '.conv.7', b.cout)]
+            for name, c in bn_list:
+                bn_tables(name, c)
+                if training:
+                    accbuf(name, c)            # forward statistics
+                    accbuf(name + '.s', c)     # BatchNorm-backward sums
         else:
             bn_tables('features.norm0', sp.c_stem)
             accbuf('features.norm0', sp.c_stem)
@@ -220,6 +220,8 @@ class Engine:
             cmax_mid = max([l.mid for b in sp.blocks for l in b.layers] + [sp.d0])
             big = max(self.M0 * sp.c_stem, self.M2 * sp.c_feat, self.M1 * cmax_mid, self.M2 * cmax_mid,
                       *[self.geo[b.res][0] * b.cout for b in sp.blocks])
+            if self.mobilenet:
+                big = max(big, self.ir_n_e1, self.ir_n_io)
             self.tmp_a = zeros(big, bf16)
             # input of the BatchNorm backward (see bn_bwd_apply): bf16 like every other activation gradient, or fp32
             self.dr_f32 = int(getattr(model, 'bn_grad_dtype', torch.bfloat16) == torch.float32 or bf16 != torch.bfloat16)
@@ -238,8 +240,8 @@ class Engine:
                     for l in blk.layers:
                         self.dz_l[l.prefix] = zeros(Mb * l.growth, bf16)
                         self.dy1_l[l.prefix] = zeros(Mb * l.mid, bf16)
-            self.coef = zeros(3 * max(sp.c_feat, cmax_mid, sp.c_stem))
-            self.dw0pad = zeros(sp.c_stem * S.STEM_KPAD)
+            self.coef = zeros(3 * max([sp.c_feat, cmax_mid, sp.c_stem] + [b.hid for b in getattr(sp, 'ir', ())]))
+            self.dw0pad = zeros(sp.c_stem * max(S.STEM_KPAD, S.STEM3_KPAD))
             n_drop = 5 * sp.d1 + sp.C_aspp
             self.dropmask = torch.ones(B * n_drop, dtype=f32, device=dev)
             self.drop_ld = n_drop
@@ -254,9 +256,10 @@ class Engine:
         self._up_bwd = None
         self._argmax = None
 
-    def _alloc_mobilenet(self, zeros, dt):
-        """Trunk buffers of the MobileNetV2 variant: two block in/out tensors (ping-pong) and the two
-        expanded tensors of an inverted-residual block, each sized for the largest block."""
+    def _alloc_mobilenet(self, zeros, dt, training):
+        """Trunk buffers of the MobileNetV2 variant.  Inference: two block in/out tensors (ping-pong) and the
+        two expanded tensors of an inverted-residual block, each sized for the largest block.  Training keeps
+        every block's expanded, depthwise, projected and output tensor for the backward pass."""
         sp = self.spec
         h, w = self.H0, self.W0
         self.stem_out = zeros(self.M0 * sp.c_stem, dt)
@@ -267,14 +270,27 @@ class Engine:
             self.ir_geom.append((h, w, ho, wo))
             n_e1 = max(n_e1, self.B * h * w * b.hid)
             n_e2 = max(n_e2, self.B * ho * wo * b.hid)
-            n_io = max(n_io, self.B * ho * wo * b.cout)
+            n_io = max(n_io, self.B * ho * wo * b.cout, self.B * h * w * b.cin)
             h, w = ho, wo
         if (h, w) != (self.H2, self.W2):
             raise ValueError('MobileNet trunk output %dx%d is not 1/8 of the input' % (h, w))
-        self.ir_io = [zeros(n_io, dt), zeros(n_io, dt)]
-        self.ir_e1 = zeros(n_e1, dt)
-        self.ir_e2 = zeros(n_e2, dt)
-        self.ir_p = zeros(n_io, dt)
+        self.ir_n_e1, self.ir_n_io = n_e1, n_io
+        if not training:
+            self.ir_io = [zeros(n_io, dt), zeros(n_io, dt)]
+            self.ir_e1 = zeros(n_e1, dt)
+            self.ir_e2 = zeros(n_e2, dt)
+            self.ir_p = zeros(n_io, dt)
+            return
+        if sp.ir[-1].residual:
+            raise NotImplementedError('MobileNet trunk whose last block has a skip connection')
+        self.ir_keep = []
+        for b, (h, w, ho, wo) in zip(sp.ir, self.ir_geom):
+            last = b is sp.ir[-1]
+            self.ir_keep.append(dict(e1=zeros(self.B * h * w * b.hid, dt), e2=zeros(self.B * ho * wo * b.hid, dt),
+                                     p=zeros(self.B * ho * wo * b.cout, dt),
+                                     out=None if last else zeros(self.B * ho * wo * b.cout, dt)))
+        self.ir_g = [zeros(n_io, dt), zeros(n_io, dt)]         # block-output gradients (ping-pong)
+        self.col3 = zeros(self.M0 * S.STEM3_KPAD, dt)          # 3x3/2 im2col rows for the stem weight gradient
 
     # ------------------------------------------------------------------ helpers
     def P(self, name):
@@ -341,6 +357,8 @@ class Engine:
 
         if self.mobilenet:
             self._build_trunk_mobilenet(ops, C)
+            if tr:
+                self._feat_stats(ops)
             self._build_head(ops, C)
             return ops
 
@@ -415,51 +433,77 @@ class Engine:
                    shift=self.bnt('features.norm5', 'shift', cf), relu=1, y=_r(A.x, sp.off_feat), ldy=A.C,
                    stat_acc=_r(self.acc['feat']) if tr else None)
         if tr:
-            # statistics of the feature channels, shared by every later ASPP norm1
-            ops.op('bn_finalize', C=cf, acc=_r(self.acc['feat']), acc_c0=0, acc_cn=cf, count=float(self.M2),
-                   mean=_r(A.mean, sp.off_feat), var=_r(A.var, sp.off_feat), rstd=_r(A.rstd, sp.off_feat),
-                   gamma=None, beta=None, running_mean=None, running_var=None, num_batches_tracked=None,
-                   momentum=0.0, eps=1e-5, use_running=0, scale=None, shift=None)
+            self._feat_stats(ops)
         self._build_head(ops, C)
         return ops
 
+    def _feat_stats(self, ops):
+        """Batch statistics of the ASPP slab's feature channels, shared by every later ASPP norm1."""
+        sp, A, cf = self.spec, self.aslab, self.spec.c_feat
+        ops.op('bn_finalize', C=cf, acc=_r(self.acc['feat']), acc_c0=0, acc_cn=cf, count=float(self.M2),
+               mean=_r(A.mean, sp.off_feat), var=_r(A.var, sp.off_feat), rstd=_r(A.rstd, sp.off_feat),
+               gamma=None, beta=None, running_mean=None, running_var=None, num_batches_tracked=None,
+               momentum=0.0, eps=1e-5, use_running=0, scale=None, shift=None)
+
     def _build_trunk_mobilenet(self, ops, C):
-        """MobileNetV2 trunk (eval mode): every BatchNorm is applied by its consumer -- in the prologue of the
-        next convolution, or by the bn_act that closes a block (which also adds the skip connection)."""
-        sp, B = self.spec, self.B
+        """MobileNetV2 trunk: every BatchNorm is applied by its consumer -- in the prologue of the next
+        convolution, or by the bn_act that closes a block (which also adds the skip connection).  In training
+        the pointwise convolutions take the batch statistics of their outputs in their epilogues; the stem and
+        the depthwise outputs get theirs from an in-place identity pass."""
+        sp, B, tr = self.spec, self.B, self.training
         n0 = sp.stem_prefix + '.1'
+
+        def acc(name):
+            return _r(self.acc[name]) if tr else None
+
+        def stats_pass(t, M, c_, name):
+            ops.op('bn_act', M=M, C=c_, x=_r(t), ldx=c_, scale=None, shift=None, relu=0, y=_r(t), ldy=c_,
+                   stat_acc=acc(name), res=None, ldres=0)
+
+        def finalize(name, c_, count):
+            self._bn_finalize(ops, name, c_, acc=acc(name), acc_c0=0, acc_cn=c_ if tr else 0, count=count)
+
         ops.op('stem3', n_img=B, H=self.H, W=self.W, x=_r(self.x_in), w=self.W16(sp.stem_prefix + '.0.weight'),
                cout=sp.c_stem, y=_r(self.stem_out), ldy=sp.c_stem)
-        self._bn_finalize(ops, n0, sp.c_stem, count=self.M0)
+        if tr:
+            stats_pass(self.stem_out, self.M0, sp.c_stem, n0)
+        finalize(n0, sp.c_stem, self.M0)
         cur, cur_c = self.stem_out, sp.c_stem
         cur_pro = dict(in_scale=self.bnt(n0, 'scale', sp.c_stem), in_shift=self.bnt(n0, 'shift', sp.c_stem), in_relu=2)
         A = self.aslab
         for i, b in enumerate(sp.ir):
             h, w, ho, wo = self.ir_geom[i]
             n1, n2, n3 = b.prefix + '.conv.1', b.prefix + '.conv.4', b.prefix + '.conv.7'
+            if tr:
+                keep = self.ir_keep[i]
+                e1, e2, pj = keep['e1'], keep['e2'], keep['p']
+            else:
+                e1, e2, pj = self.ir_e1, self.ir_e2, self.ir_p
             C(n_img=B, H=h, W=w, cin=b.cin, cout=b.hid, taps=1, dil=1, x=_r(cur), ldx=cur_c,
-              w=self.W16(b.prefix + '.conv.0.weight'), y=_r(self.ir_e1), ldy=b.hid, **cur_pro)
-            self._bn_finalize(ops, n1, b.hid, count=B * h * w)
-            ops.op('dwconv', n_img=B, H=h, W=w, C=b.hid, stride=b.stride, dil=b.dil, x=_r(self.ir_e1), ldx=b.hid,
+              w=self.W16(b.prefix + '.conv.0.weight'), y=_r(e1), ldy=b.hid, stat_acc=acc(n1), **cur_pro)
+            finalize(n1, b.hid, B * h * w)
+            ops.op('dwconv', n_img=B, H=h, W=w, C=b.hid, stride=b.stride, dil=b.dil, x=_r(e1), ldx=b.hid,
                    in_scale=self.bnt(n1, 'scale', b.hid), in_shift=self.bnt(n1, 'shift', b.hid), in_relu=2,
-                   w=self.W16(b.prefix + '.conv.3.weight'), y=_r(self.ir_e2), ldy=b.hid)
-            self._bn_finalize(ops, n2, b.hid, count=B * ho * wo)
-            C(n_img=B, H=ho, W=wo, cin=b.hid, cout=b.cout, taps=1, dil=1, x=_r(self.ir_e2), ldx=b.hid,
+                   w=self.W16(b.prefix + '.conv.3.weight'), y=_r(e2), ldy=b.hid)
+            if tr:
+                stats_pass(e2, B * ho * wo, b.hid, n2)
+            finalize(n2, b.hid, B * ho * wo)
+            C(n_img=B, H=ho, W=wo, cin=b.hid, cout=b.cout, taps=1, dil=1, x=_r(e2), ldx=b.hid,
               w=self.W16(b.prefix + '.conv.6.weight'), in_scale=self.bnt(n2, 'scale', b.hid),
-              in_shift=self.bnt(n2, 'shift', b.hid), in_relu=2, y=_r(self.ir_p), ldy=b.cout)
-            self._bn_finalize(ops, n3, b.cout, count=B * ho * wo)
+              in_shift=self.bnt(n2, 'shift', b.hid), in_relu=2, y=_r(pj), ldy=b.cout, stat_acc=acc(n3))
+            finalize(n3, b.cout, B * ho * wo)
             last = i == len(sp.ir) - 1
             if last:      # ReLU(trunk) goes straight into the ASPP slab (the in-place ReLU heading ASPP_3)
                 dst, ldd = _r(A.x, sp.off_feat), A.C
             else:
-                nxt = self.ir_io[i % 2]
+                nxt = keep['out'] if tr else self.ir_io[i % 2]
                 dst, ldd = _r(nxt), b.cout
             res = (_r(cur), cur_c) if b.residual else (None, 0)
             if b.residual and cur_pro:
                 raise AssertionError('residual block fed by an unnormalised tensor')
-            ops.op('bn_act', M=B * ho * wo, C=b.cout, x=_r(self.ir_p), ldx=b.cout, scale=self.bnt(n3, 'scale', b.cout),
-                   shift=self.bnt(n3, 'shift', b.cout), relu=1 if last else 0, y=dst, ldy=ldd, stat_acc=None,
-                   res=res[0], ldres=res[1])
+            ops.op('bn_act', M=B * ho * wo, C=b.cout, x=_r(pj), ldx=b.cout, scale=self.bnt(n3, 'scale', b.cout),
+                   shift=self.bnt(n3, 'shift', b.cout), relu=1 if last else 0, y=dst, ldy=ldd,
+                   stat_acc=_r(self.acc['feat']) if (tr and last) else None, res=res[0], ldres=res[1])
             if not last:
                 cur, cur_c, cur_pro = nxt, b.cout, {}
 
@@ -619,6 +663,10 @@ class Engine:
                   w=self.WT16(a.prefix + '.conv1.weight'), epi_relu=1, ref=_r(A.x, a.off_in), ldref=A.C,
                   g=_r(A.g, a.off_in), ldg=A.C, g_accumulate=1)
 
+        if self.mobilenet:
+            self._build_backward_mobilenet(ops, C, WG, gradx, slab_extract, bn_bwd, bn_apply, zero)
+            return ops
+
         # ---- ReLU + norm5
         cf = sp.c_feat
         n5 = 'features.norm5'
@@ -738,6 +786,90 @@ class Engine:
         ops.op('copy2d', src=_r(self.dw0pad), dst=self.PG('features.conv0.weight'), n=0, value=0, lds=S.STEM_KPAD,
                ldd=S.STEM_K, rows=cs, cols=S.STEM_K, dst_cols=S.STEM_K, accumulate=1)
         return ops
+
+    def _build_backward_mobilenet(self, ops, C, WG, gradx, slab_extract, bn_bwd, bn_apply, zero):
+        """Backward of the MobileNetV2 trunk, last block first.  Per block: BatchNorm backward of the projection
+        (sums taken while the incoming gradient is read out), projection weight/data gradients (the data
+        gradient masked by the ReLU6 of the depthwise BatchNorm and reduced to that BatchNorm's sums in the
+        convolution epilogue), depthwise weight/data gradients (same fusion for the expansion BatchNorm),
+        expansion weight/data gradients, skip-connection add."""
+        sp, B, A = self.spec, self.B, self.aslab
+        dz, dr, dy1 = self.tmp_a, self.tmp_b, self.tmp_c
+        n0 = sp.stem_prefix + '.1'
+        g_out = None                      # gradient w.r.t. the current block's output, bf16 [M][cout]
+        for i in reversed(range(len(sp.ir))):
+            b = sp.ir[i]
+            h, w, ho, wo = self.ir_geom[i]
+            Mi, Mo = B * h * w, B * ho * wo
+            keep = self.ir_keep[i]
+            e1, e2, pj = keep['e1'], keep['e2'], keep['p']
+            n1, n2, n3 = b.prefix + '.conv.1', b.prefix + '.conv.4', b.prefix + '.conv.7'
+            first, last = i == 0, i == len(sp.ir) - 1
+            if first:
+                x_in, c_in = self.stem_out, sp.c_stem
+                pro = dict(in_scale=self.bnt(n0, 'scale', sp.c_stem), in_shift=self.bnt(n0, 'shift', sp.c_stem), in_relu=2)
+            else:
+                x_in, c_in, pro = self.ir_keep[i - 1]['out'], b.cin, {}
+            # ---- BatchNorm of the projection
+            stat3 = dict(r_mean=self.bnt(n3, 'mean', b.cout), r_rstd=self.bnt(n3, 'rstd', b.cout), s_acc=_r(self.acc[n3 + '.s']),
+                         dz_f32=self.dr_f32)
+            if last:      # from the ASPP slab, through the ReLU that heads the ASPP stack
+                slab_extract(A, sp.off_feat, b.cout, dr, relu=1, yref=_r(pj), ldyref=b.cout,
+                             r_scale=self.bnt(n3, 'scale', b.cout), r_shift=self.bnt(n3, 'shift', b.cout), **stat3)
+            else:
+                gradx(M=Mo, C=b.cout, g=_r(g_out), ldg=b.cout, g_bf16=1, yref=_r(pj), ldyref=b.cout, dz=_r(dr), lddz=b.cout, **stat3)
+            bn_bwd(n3, b.cout, n3 + '.s', Mo, 0)
+            bn_apply(b.cout, Mo, dr, pj, dz)
+            # ---- projection (1x1, hid -> cout)
+            WG(n_img=B, H=ho, W=wo, cin=b.hid, cout=b.cout, taps=1, dil=1, x=_r(e2), ldx=b.hid,
+               in_scale=self.bnt(n2, 'scale', b.hid), in_shift=self.bnt(n2, 'shift', b.hid), in_relu=2, dz=_r(dz),
+               lddz=b.cout, dw=self.PG(b.prefix + '.conv.6.weight'))
+            C(n_img=B, H=ho, W=wo, cin=b.cout, cout=b.hid, taps=1, dil=1, x=_r(dz), ldx=b.cout,
+              w=self.WT16(b.prefix + '.conv.6.weight'), y=_r(dr), ldy=b.hid, y_f32=self.dr_f32, epi_relu=2, ref=_r(e2),
+              ldref=b.hid, e_scale=self.bnt(n2, 'scale', b.hid), e_shift=self.bnt(n2, 'shift', b.hid),
+              e_mean=self.bnt(n2, 'mean', b.hid), e_rstd=self.bnt(n2, 'rstd', b.hid), s_acc=_r(self.acc[n2 + '.s']))
+            bn_bwd(n2, b.hid, n2 + '.s', Mo, 0)
+            bn_apply(b.hid, Mo, dr, e2, dy1)
+            # ---- depthwise 3x3
+            dwf = dict(n_img=B, H=h, W=w, C=b.hid, stride=b.stride, dil=b.dil, x=_r(e1), ldx=b.hid,
+                       in_scale=self.bnt(n1, 'scale', b.hid), in_shift=self.bnt(n1, 'shift', b.hid), in_relu=2,
+                       dy=_r(dy1), lddy=b.hid)
+            ops.op('dw_wgrad', w=None, dx=None, lddx=0, dx_f32=0, e_mean=None, e_rstd=None, s_acc=None,
+                   dw=self.PG(b.prefix + '.conv.3.weight'), **dwf)
+            ops.op('dw_bwd_data', w=self.W16(b.prefix + '.conv.3.weight'), dx=_r(dr), lddx=b.hid, dx_f32=self.dr_f32,
+                   e_mean=self.bnt(n1, 'mean', b.hid), e_rstd=self.bnt(n1, 'rstd', b.hid), s_acc=_r(self.acc[n1 + '.s']),
+                   dw=None, **dwf)
+            bn_bwd(n1, b.hid, n1 + '.s', Mi, 0)
+            bn_apply(b.hid, Mi, dr, e1, dz)
+            # ---- expansion (1x1, cin -> hid)
+            WG(n_img=B, H=h, W=w, cin=c_in, cout=b.hid, taps=1, dil=1, x=_r(x_in), ldx=c_in, dz=_r(dz), lddz=b.hid,
+               dw=self.PG(b.prefix + '.conv.0.weight'), **pro)
+            dg = dict(n_img=B, H=h, W=w, cin=b.hid, cout=c_in, taps=1, dil=1, x=_r(dz), ldx=b.hid,
+                      w=self.WT16(b.prefix + '.conv.0.weight'))
+            if first:     # through the stem's ReLU6 + BatchNorm
+                C(y=_r(dr), ldy=c_in, y_f32=self.dr_f32, epi_relu=2, ref=_r(self.stem_out), ldref=c_in,
+                  e_scale=self.bnt(n0, 'scale', c_in), e_shift=self.bnt(n0, 'shift', c_in),
+                  e_mean=self.bnt(n0, 'mean', c_in), e_rstd=self.bnt(n0, 'rstd', c_in), s_acc=_r(self.acc[n0 + '.s']), **dg)
+            elif b.residual:
+                g_in = self.ir_g[i % 2]
+                C(y=_r(dy1), ldy=c_in, **dg)
+                ops.op('bn_act', M=Mi, C=c_in, x=_r(dy1), ldx=c_in, scale=None, shift=None, relu=0, y=_r(g_in), ldy=c_in,
+                       stat_acc=None, res=_r(g_out), ldres=c_in)
+                g_out = g_in
+            else:
+                g_in = self.ir_g[i % 2]
+                C(y=_r(g_in), ldy=c_in, **dg)
+                g_out = g_in
+        # ---- stem: BatchNorm backward, weight gradient as a GEMM over 3x3/2 im2col rows
+        cs = sp.c_stem
+        bn_bwd(n0, cs, n0 + '.s', self.M0, 0)
+        bn_apply(cs, self.M0, dr, self.stem_out, dz)
+        ops.op('stem3_col', n_img=B, H=self.H, W=self.W, x=_r(self.x_in), col=_r(self.col3), ldcol=S.STEM3_KPAD)
+        zero(self.dw0pad)
+        WG(n_img=B, H=self.H0, W=self.W0, cin=S.STEM3_KPAD, cout=cs, taps=1, dil=1, x=_r(self.col3), ldx=S.STEM3_KPAD,
+           dz=_r(dz), lddz=cs, dw=_r(self.dw0pad))
+        ops.op('copy2d', src=_r(self.dw0pad), dst=self.PG(sp.stem_prefix + '.0.weight'), n=0, value=0, lds=S.STEM3_KPAD,
+               ldd=S.MOBILENET_STEM_K, rows=cs, cols=S.MOBILENET_STEM_K, dst_cols=S.MOBILENET_STEM_K, accumulate=1)
 
     # ------------------------------------------------------------------ full-resolution logits API
     def build_up_fwd(self):

@@ -39,6 +39,7 @@ MOBILENET_ROWS = (
 )
 MOBILENET_STEM = 32
 MOBILENET_STEM_K = 27     # 3 * 3 * 3
+STEM3_KPAD = 32           # row width of the 3x3/2 im2col (stem weight gradient)
 
 
 def is_mobilenet_cfg(cfg):

@@ -76,7 +76,8 @@ def op_conv(f):
         ref = _view(f['ref'], M, cout, f['ldref']).to(torch.float32)
     if f['epi_relu']:
         pre = ref * _vec(f['e_scale'], cout) + _vec(f['e_shift'], cout) if f['e_scale'] is not None else ref
-        v = torch.where(pre > 0, v, torch.zeros_like(v))
+        keep = (pre > 0) & (pre < 6) if f['epi_relu'] == 2 else pre > 0
+        v = torch.where(keep, v, torch.zeros_like(v))
     if f['s_acc'] is not None:
         xhat = (ref - _vec(f['e_mean'], cout)) * _vec(f['e_rstd'], cout)
         sld = f.get('s_ld', 0) or cout
@@ -226,7 +227,8 @@ def op_grad_extract(f):
         y = _view(f['yref'], M, C, f['ldyref']).to(torch.float32)
     if f['relu']:
         pre = y * _vec(f['r_scale'], C) + _vec(f['r_shift'], C) if f['r_scale'] is not None else y
-        v = torch.where(pre > 0, v, torch.zeros_like(v))
+        keep = (pre > 0) & (pre < 6) if f['relu'] == 2 else pre > 0
+        v = torch.where(keep, v, torch.zeros_like(v))
     _view(f['dz'], M, C, f['lddz']).copy_(v if f['dz_f32'] else v.to(bf16))
     if f['s_acc'] is not None:
         xh = (y - _vec(f['r_mean'], C)) * _vec(f['r_rstd'], C)
@@ -304,6 +306,64 @@ def op_dwconv(f):
     y = F.conv2d(a4, w, stride=st, padding=dil, dilation=dil, groups=C)
     y = y.permute(0, 2, 3, 1).reshape(-1, C)
     _view(f['y'], y.shape[0], C, f['ldy']).copy_(y.to(bf16))
+
+
+def _dw_act(f, x, C):
+    a = x
+    if f['in_scale'] is not None:
+        a = a * _vec(f['in_scale'], C) + _vec(f['in_shift'], C)
+    pre = a
+    if f['in_relu']:
+        a = a.clamp_min(0)
+    if f['in_relu'] == 2:
+        a = a.clamp_max(6)
+    if f['in_scale'] is not None or f['in_relu']:
+        a = _rbf(a)
+    return a, pre
+
+
+def op_dw_bwd_data(f):
+    n, H, W, C, st, dil = f['n_img'], f['H'], f['W'], f['C'], f['stride'], f['dil']
+    Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
+    dy = _view(f['dy'], n * Ho * Wo, C, f['lddy']).to(torch.float32).view(n, Ho, Wo, C).permute(0, 3, 1, 2)
+    w = _view(f['w'], C, 9, 9).to(torch.float32).view(C, 1, 3, 3)
+    da = torch.nn.grad.conv2d_input((n, C, H, W), w, dy, stride=st, padding=dil, dilation=dil, groups=C)
+    v = da.permute(0, 2, 3, 1).reshape(n * H * W, C)
+    x = None
+    if f['in_relu'] or f['s_acc'] is not None:
+        x = _view(f['x'], n * H * W, C, f['ldx']).to(torch.float32)
+    if f['in_relu']:
+        _, pre = _dw_act(f, x, C)
+        keep = (pre > 0) & (pre < 6) if f['in_relu'] == 2 else pre > 0
+        v = torch.where(keep, v, torch.zeros_like(v))
+    _view(f['dx'], n * H * W, C, f['lddx']).copy_(v if f['dx_f32'] else v.to(bf16))
+    if f['s_acc'] is not None:
+        xh = (x - _vec(f['e_mean'], C)) * _vec(f['e_rstd'], C)
+        acc = _view(f['s_acc'], R, 2 * C, 2 * C)
+        acc[0, :C] += v.sum(0)
+        acc[0, C:] += (v * xh).sum(0)
+
+
+def op_dw_wgrad(f):
+    n, H, W, C, st, dil = f['n_img'], f['H'], f['W'], f['C'], f['stride'], f['dil']
+    Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
+    x = _view(f['x'], n * H * W, C, f['ldx']).to(torch.float32)
+    a, _ = _dw_act(f, x, C)
+    a4 = a.view(n, H, W, C).permute(0, 3, 1, 2)
+    dy = _view(f['dy'], n * Ho * Wo, C, f['lddy']).to(torch.float32).view(n, Ho, Wo, C).permute(0, 3, 1, 2)
+    gw = torch.nn.grad.conv2d_weight(a4, (C, 1, 3, 3), dy, stride=st, padding=dil, dilation=dil, groups=C)
+    _view(f['dw'], C, 9, 9).add_(gw.reshape(C, 9))
+
+
+def op_stem3_col(f):
+    n, H, W = f['n_img'], f['H'], f['W']
+    x = torch.as_strided(f['x'].t, (n, 3, H, W), (3 * H * W, H * W, W, 1), f['x'].off)
+    cols = F.unfold(x, 3, padding=1, stride=2)               # n, 3*9 (ci, ky, kx), L
+    L = cols.shape[-1]
+    cols = cols.view(n, 3, 9, L).permute(0, 3, 2, 1).reshape(n * L, 27)       # (ky,kx) major, ci minor
+    out = _view(f['col'], n * L, f['ldcol'], f['ldcol'])
+    out.zero_()
+    out[:, :27] = cols.to(bf16)
 
 
 def op_up2_fwd(f):
@@ -465,6 +525,7 @@ OPS = {
     'maxpool_fwd': op_maxpool_fwd, 'maxpool_bwd': op_maxpool_bwd, 'upce': op_upce, 'ce_finalize': op_ce_finalize,
     'up_fwd': op_up_fwd, 'up_bwd': op_up_bwd, 'up_argmax': op_up_argmax, 'memset': op_memset, 'copy2d': op_copy2d,
     'stem3': op_stem3, 'dwconv': op_dwconv, 'up2_fwd': op_up2_fwd, 'up2_bwd': op_up2_bwd,
+    'dw_bwd_data': op_dw_bwd_data, 'dw_wgrad': op_dw_wgrad, 'stem3_col': op_stem3_col,
 }
 
 
