@@ -17,6 +17,9 @@ int dsaspp_dgrad_group_launch(const dsaspp_conv_desc& d, hipStream_t s);
 // halo-patch 3x3 convolution with few output channels (conv3x3_halo.hip): same return convention
 int dsaspp_conv3x3_halo_launch(const dsaspp_conv_desc& d, hipStream_t s);
 
+// streaming BN-ReLU-1x1 forward for cout <= 192 (conv1x1_stream.hip): same return convention
+int dsaspp_conv1x1_stream_launch(const dsaspp_conv_desc& d, hipStream_t s);
+
 // fp32 forms (descriptor dtype == 1) of the eval-mode forward kernels (fp32_path.hip); called by the public entry
 // points after their argument checks
 int dsaspp_f32_conv(const dsaspp_conv_desc& d, hipStream_t s);

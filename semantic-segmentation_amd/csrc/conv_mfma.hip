@@ -726,6 +726,10 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
             if (rc >= 0) return rc;
         }
     }
+    if (d.taps == 1) {   // BN-ReLU-1x1 forward with few output channels: streaming kernel (DSASPP_STREAM1X1=0 disables it)
+        const int rc = dsaspp_conv1x1_stream_launch(d, s);
+        if (rc >= 0) return rc;
+    }
     const int co = d.cout;
     {   // experiment hook: DSASPP_CONV_TILE=<id> forces a tile for launches with cout > 64
         static const int forced = [] { const char* e = getenv("DSASPP_CONV_TILE"); return e ? atoi(e) : 0; }();

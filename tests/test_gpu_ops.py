@@ -68,6 +68,12 @@ def check_conv(f, tol=2e-2):
 
 
 CONV_CASES = [
+    # BN-ReLU-1x1 forward with cout <= 192 (streaming form): slab-strided input, K tail, row tail, two output widths,
+    # output into a channel slice, with and without statistics
+    dict(n=2, H=23, W=31, cin=1248, cout=192, taps=1, dil=1, ldx=1296, stats=True),
+    dict(n=1, H=17, W=19, cin=200, cout=128, taps=1, dil=1, ldx=208, ldy=160, yoff=16, stats=True),
+    dict(n=3, H=16, W=16, cin=64, cout=96, taps=1, dil=1),
+    dict(n=1, H=40, W=52, cin=392, cout=184, taps=1, dil=1, xoff=8, stats=True),
     # merged-K form (3x3, raw input with fewer channels than one K-step): K = 9*cin laid end to end
     dict(n=2, H=11, W=9, cin=32, cout=128, taps=9, dil=2, scale=False, relu=False, epi_relu=True, e_scale=True, s_acc=True),
     dict(n=1, H=13, W=21, cin=56, cout=192, taps=9, dil=1, scale=False, relu=False, ldx=64, stats=True),

@@ -14,7 +14,7 @@ def klass(name):
     n = name.replace(' ', '')
     for c in profiling.CLASSES[1:]:
         stem = c[:-1] + ',' if c.endswith('>') else c
-        if stem in n or (not c.endswith('>') and c in n):
+        if stem in n or c + '(' in n or (not c.endswith('>') and c in n):
             return c
     return None
 
