@@ -104,16 +104,12 @@ def test_conv(case):
     check_conv(conv_fields(seed=case, **CONV_CASES[case]))
 
 
-@pytest.mark.parametrize('n_src', [2, 3, 4])
-def test_conv_multi_source(n_src):
-    """Several consumer layers' 1x1 data gradients summed into the gradient slab in one pass, each with its
-    own ReLU mask, scale and BatchNorm-backward sums (written into a slice of a wider accumulator)."""
-    cout, cin, sld = 200, 192, 264
-    f = conv_fields(n=2, H=10, W=12, cin=cin, cout=cout, taps=1, dil=1, scale=False, relu=False, epi_relu=True,
-                    e_scale=True, s_acc=True, g=True, g_acc=True, ldy=400, yoff=8, seed=40 + n_src)
+def multi_source_fields(n_src, n=2, H=10, W=12, cin=192, cout=200, sld=264, g_bf16=False, g_acc=True, stats=True):
+    f = conv_fields(n=n, H=H, W=W, cin=cin, cout=cout, taps=1, dil=1, scale=False, relu=False, epi_relu=True,
+                    e_scale=True, s_acc=True, g=True, g_acc=g_acc, g_bf16=g_bf16, ldy=cout + 64, yoff=8, seed=40 + n_src)
     gen = torch.Generator().manual_seed(50 + n_src)
-    M = 2 * 10 * 12
-    f['s_acc'] = Ref(torch.zeros(R * 2 * sld + 16), 16)
+    M = n * H * W
+    f['s_acc'] = Ref(torch.zeros(R * 2 * sld + 16), 16) if stats else None
     f['s_ld'] = sld
     f['n_src'] = n_src
     for k in range(1, 4):
@@ -122,15 +118,40 @@ def test_conv_multi_source(n_src):
         f['w%d' % k] = Ref(bf(torch.randn(cout * cin, generator=gen) * cin ** -0.5)) if on else None
         f['es%d' % k] = Ref(torch.rand(cout, generator=gen) + 0.5) if on else None
         f['eh%d' % k] = Ref(torch.randn(cout, generator=gen) * 0.3) if on else None
-        f['sa%d' % k] = Ref(torch.zeros(R * 2 * (sld + 8 * k))) if on else None
+        f['sa%d' % k] = Ref(torch.zeros(R * 2 * (sld + 8 * k))) if on and stats else None
         f['sl%d' % k] = sld + 8 * k if on else 0
+    return f
+
+
+def check_multi_source(f, n_src, stats=True):
     out = run_both('conv', f)
     close(out['g'][0], out['g'][1], 2e-2, 'conv_multi.g')
+    if not stats:
+        return
     c, g = out['s_acc']
     close(c[16:].view(R, -1).sum(0), g[16:].view(R, -1).sum(0), 2e-2, 'conv_multi.s_acc')
     for k in range(1, n_src):
         c, g = out['sa%d' % k]
         close(c.view(R, -1).sum(0), g.view(R, -1).sum(0), 2e-2, 'conv_multi.sa%d' % k)
+
+
+@pytest.mark.parametrize('n_src', [2, 3, 4])
+def test_conv_multi_source(n_src):
+    """Several consumer layers' 1x1 data gradients summed into the gradient slab in one pass, each with its
+    own ReLU mask, scale and BatchNorm-backward sums (written into a slice of a wider accumulator)."""
+    check_multi_source(multi_source_fields(n_src), n_src)
+
+
+@pytest.mark.parametrize('n_src,cin,g_bf16,g_acc,stats', [
+    (4, 192, True, True, True), (4, 192, False, True, True), (3, 192, True, False, True), (2, 128, True, True, True),
+    (1, 128, False, True, True), (1, 64, True, True, True), (2, 64, True, True, False), (4, 320, True, True, True)])
+def test_dgrad_group_many_tiles(n_src, cin, g_bf16, g_acc, stats, monkeypatch):
+    """The persistent grouped data-gradient kernel with eight blocks only, so that every block walks several
+    (pixel tile, channel tile) pairs: the side loads of tile k+1 are requested while tile k finishes, and the
+    hand-counted waits see every combination of K-steps per tile (1..12), partial pixel and channel tiles."""
+    monkeypatch.setenv('DSASPP_DGG_GRID', '8')
+    f = multi_source_fields(n_src, n=3, H=20, W=33, cin=cin, cout=328, sld=400, g_bf16=g_bf16, g_acc=g_acc, stats=stats)
+    check_multi_source(f, n_src, stats)
 
 
 def test_conv_s_slice():
