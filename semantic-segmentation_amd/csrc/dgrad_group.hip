@@ -42,7 +42,7 @@ constexpr int ROWF = TQ + 4;
 constexpr int PATCH_BYTES = NW * 16 * ROWF * 4;
 constexpr int PAR_ROWS = 10;                                             // es[4], eh[4], mean, rstd
 constexpr int PAR_BYTES = PAR_ROWS * BQ * 4;
-constexpr int SRED_BYTES = 4 * 2 * BQ * 4;
+constexpr int SRED_BYTES = WP * 4 * 2 * BQ * 4;                        // [pixel half of the tile][source][which sum][channel]
 constexpr int LDS_BYTES = NS * STAGE + PATCH_BYTES + PAR_BYTES + SRED_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(MQ == 2 && MP == 4, "register tie statements are written for a 64 x 32 wave tile");
@@ -189,6 +189,8 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
     const int rep = blockIdx.x % DS_R;
     float* stage = patch + wave * (16 * ROWF);
     const int er = lane >> 3, ec = lane & 7;
+    const bool b0 = fr & 1, b1 = fr & 2, b2 = fr & 4, b3 = fr & 8;
+    const int sred_lane = ((fr >> 2) & 1) * BQ + wq * TQ + (fr >> 3) * 16 + fc * 4 + (fr & 3);      // [which sum][channel] of the total this lane keeps
 
     // ---- per-tile side loads
     // parameters: 20 half rows (10 rows x 2 x 64 channels), one DMA instruction each, 4 B per lane
@@ -244,7 +246,6 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
 
     // ---- prologue: the first tile's side loads, then DEPTH operand stages (the side loads are older than every
     //      stage, so the first step's wait covers them)
-    for (int c = tid; c < 4 * 2 * BQ; c += NT) sred[c] = 0.f;
     {
         int pb, qb;
         tile_coords(0, pb, qb);
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
         tile_coords(k, p_base, q_base);
         const bool ptail = p_base + BP > M;
         const bool full = !ptail && q_base + BQ <= cout;
-        f32x4 tot[MQ][MP], xh[MQ][MP];
+        f32x4 tot[MQ][MP];
 #pragma unroll
         for (int i = 0; i < MQ; ++i)
 #pragma unroll
@@ -321,19 +322,6 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
                 // the reference loads have landed (waited for above); from here on their registers are ordinary values
                 asm volatile("" : "+v"(rfm[0][0]), "+v"(rfm[0][1]), "+v"(rfm[0][2]), "+v"(rfm[0][3]),
                                   "+v"(rfm[1][0]), "+v"(rfm[1][1]), "+v"(rfm[1][2]), "+v"(rfm[1][3]));
-                // normalised reference activations, shared by every source's sums
-#pragma unroll
-                for (int i = 0; i < MQ; ++i) {
-                    const int cl = wq * TQ + i * 16 + fc * 4;
-                    const f32x4 mu4 = *reinterpret_cast<const f32x4*>(par + 8 * BQ + cl);
-                    const f32x4 rs4 = *reinterpret_cast<const f32x4*>(par + 9 * BQ + cl);
-#pragma unroll
-                    for (int j = 0; j < MP; ++j) {
-                        const u32x2 rr = rfm[i][j];
-                        xh[i][j] = f32x4{(bf_lo(rr.x) - mu4[0]) * rs4[0], (bf_hi(rr.x) - mu4[1]) * rs4[1],
-                                         (bf_lo(rr.y) - mu4[2]) * rs4[2], (bf_hi(rr.y) - mu4[3]) * rs4[3]};
-                    }
-                }
             }
             if (ptail) {
                 // rows past the last pixel were computed from a repeated row: they must not reach the sums
@@ -348,13 +336,17 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
             }
             // ---- this source's product: ReLU mask, BatchNorm-backward sums, scaled add into the total.
             //      Channels past cout carry finite garbage through their own columns only; nothing of them is stored.
+            // The sums are sum(v) and sum(v * xhat), xhat = (ref - mean) * rstd: the second one is accumulated against the
+            // raw reference value and corrected per channel afterwards, rstd * (sum(v * ref) - mean * sum(v)).
             const bool want_s = a.sa[s] != nullptr;
+            f32x4 s1[MQ], s2[MQ];
 #pragma unroll
             for (int i = 0; i < MQ; ++i) {
                 const int cl = wq * TQ + i * 16 + fc * 4;
                 const f32x4 sc4 = *reinterpret_cast<const f32x4*>(par + s * BQ + cl);
                 const f32x4 sh4 = *reinterpret_cast<const f32x4*>(par + (4 + s) * BQ + cl);
-                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s1[i][e] = 0.f, s2[i][e] = 0.f;
 #pragma unroll
                 for (int j = 0; j < MP; ++j) {
                     const u32x2 rr = rfm[i][j];
@@ -363,25 +355,41 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
                     for (int e = 0; e < 4; ++e) {
                         const float pre = fmaf(rf[e], sc4[e], sh4[e]);
                         const float v = pre > 0.f ? acc[i][j][e] : 0.f;
-                        s1[e] += v;
-                        s2[e] = fmaf(v, xh[i][j][e], s2[e]);
+                        s1[i][e] += v;
+                        s2[i][e] = fmaf(v, rf[e], s2[i][e]);
                         tot[i][j][e] = fmaf(v, sc4[e], tot[i][j][e]);
                     }
                 }
-                if (want_s) {
+            }
+            if (want_s) {
+#pragma unroll
+                for (int i = 0; i < MQ; ++i) {
+                    const int cl = wq * TQ + i * 16 + fc * 4;
+                    const f32x4 mu4 = *reinterpret_cast<const f32x4*>(par + 8 * BQ + cl);
+                    const f32x4 rs4 = *reinterpret_cast<const f32x4*>(par + 9 * BQ + cl);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        s1[e] = row16_sum(s1[e]);
-                        s2[e] = row16_sum(s2[e]);
-                    }
-                    if (fr == 0) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            atomicAdd(sred + (s * 2) * BQ + cl + e, s1[e]);
-                            atomicAdd(sred + (s * 2 + 1) * BQ + cl + e, s2[e]);
-                        }
+                        s2[i][e] = rs4[e] * fmaf(-mu4[e], s1[i][e], s2[i][e]);
+                        s1[i][e] = row16_sum(s1[i][e]);
+                        s2[i][e] = row16_sum(s2[i][e]);
                     }
                 }
+                // every lane of a row now holds all 16 totals of its four channels x two fragments x two sums: lane fr keeps
+                // total number fr (bit 3: fragment, bit 2: which sum, bits 1..0: channel) and stores it into the wave's own
+                // slots of the table (plain store: nobody else writes them; LDS float atomics cost as much per lane as
+                // sixteen four-lane instructions did)
+                float t2[MQ][2];
+#pragma unroll
+                for (int i = 0; i < MQ; ++i) {
+                    const float p0 = s1[i][0], p1 = s1[i][1], p2 = s1[i][2], p3 = s1[i][3];
+                    const float r0 = s2[i][0], r1 = s2[i][1], r2 = s2[i][2], r3 = s2[i][3];
+                    const float a0 = b0 ? p1 : p0, a1 = b0 ? p3 : p2;
+                    const float c0 = b0 ? r1 : r0, c1 = b0 ? r3 : r2;
+                    t2[i][0] = b1 ? a1 : a0;
+                    t2[i][1] = b1 ? c1 : c0;
+                }
+                const float u0 = b2 ? t2[0][1] : t2[0][0], u1 = b2 ? t2[1][1] : t2[1][0];
+                sred[(wp * 4 + s) * 2 * BQ + sred_lane] = b3 ? u1 : u0;
             }
         }
 
@@ -397,8 +405,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
                 const int half = (tid >> 7) & 1, cc = tid & (BQ - 1);
                 float* sa = a.sa[s];
                 const int sl = a.sl[s];
-                if (sa && q_base + cc < cout) atomicAdd(sa + (size_t)rep * 2 * sl + half * sl + q_base + cc, sred[c]);
-                sred[c] = 0.f;
+                if (sa && q_base + cc < cout) atomicAdd(sa + (size_t)rep * 2 * sl + half * sl + q_base + cc, sred[c] + sred[4 * 2 * BQ + c]);
             }
         }
         const bool has_next = k + 1 < ntile;
