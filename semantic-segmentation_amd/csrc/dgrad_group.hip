@@ -87,12 +87,13 @@ __device__ __forceinline__ void wait_vm(int c) {
     else if (c >= 20) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
     else if (c >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
     else if (c >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else if (c >= 11) asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory");
     else if (c >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     else if (c >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-template <bool ACCG, bool GBF16>
+template <bool ACCG, bool GBF16, int KS>
 __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;
@@ -101,14 +102,12 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
     float* sred = reinterpret_cast<float*>(smem + NS * STAGE + PATCH_BYTES + PAR_BYTES);
     typedef typename std::conditional<GBF16, u32x2, f32x4>::type gvec_t;      // 4 slab values of a lane
     constexpr int GB = GBF16 ? 2 : 4;                                        // bytes per slab element
-    constexpr int NE2 = ACCG ? N_G : 0;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cin = a.cin, cout = a.cout, M = a.M, nQ = a.nQ;
     const int ksteps = cin / BK;
     const int nsrc = a.nsrc;
-    const int T = nsrc * ksteps;                     // K-steps per tile
 
     // ---- this block's tile sequence: XCD x = blockIdx % 8 owns the pixel tiles pt = x (mod 8)
     const int xcd = blockIdx.x & 7, jblk = blockIdx.x >> 3, g8 = gridDim.x >> 3;
@@ -251,7 +250,6 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
         tile_coords(0, pb, qb);
         issue_par(qb);
         issue_ref(pb, qb);
-        if (ACCG) issue_gold(pb, qb);
         if (!ACCG) {
 #pragma unroll
             for (int j = 0; j < MP; ++j)
@@ -276,120 +274,186 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
 #pragma unroll
             for (int j = 0; j < MP; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+        // ---- one K-step: wait for its stage, barrier, request the stage three steps ahead, 12 fragment reads, 16 MFMAs
         int u = 0;
-        for (int s = 0; s < nsrc; ++s) {
-            f32x4 acc[MQ][MP];
+        const unsigned char* As;
+        auto kstep_head = [&]() {
+            // stage of this step landed (this wave's DMAs), then everybody's; the barrier also says every wave
+            // is done reading the previous stage, whose ring slot the next DMA overwrites.  The last step of the
+            // first source also waits for the tile's side loads (parameters visible to all waves after its barrier).
+            int c = 8 + x1 + x2 + x3;
+            if (k > 0 && u == ksteps - 1) {
+                const int cb = e1_bound + 4 * u;
+                c = c < cb ? c : cb;
+            }
+            wait_vm(c);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            x3 = x2;
+            x2 = x1;
+            x1 = 0;
+            ++u;
+            As = ring + ((c_slot + NS - DEPTH) & (NS - 1)) * STAGE;
+            issue();
+        };
+        auto kstep_mma = [&](f32x4 (&acc)[MQ][MP]) {
+            const unsigned char* Ws = As + BP * 128;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int fo = ks ? frag_off1 : frag_off0;
+                bf16x8 af[MP], wf[MQ];
+#pragma unroll
+                for (int j = 0; j < MP; ++j)
+                    af[j] = *reinterpret_cast<const bf16x8*>(As + (wp * TP + j * 16) * 128 + fo);
+#pragma unroll
+                for (int i = 0; i < MQ; ++i)
+                    wf[i] = *reinterpret_cast<const bf16x8*>(Ws + (wq * TQ + i * 16) * 128 + fo);
+#pragma unroll
+                for (int i = 0; i < MQ; ++i)
+#pragma unroll
+                    for (int j = 0; j < MP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                if (KS > 0 && ks == 0) __builtin_amdgcn_sched_barrier(0x008);      // only MFMAs may cross: the second half's fragments are
+                                                                                 // not fetched into registers the first half still needs
+            }
+        };
+        auto kstep = [&](f32x4 (&acc)[MQ][MP]) {
+            kstep_head();
+            kstep_mma(acc);
+        };
+        auto zero = [&](f32x4 (&acc)[MQ][MP]) {
 #pragma unroll
             for (int i = 0; i < MQ; ++i)
 #pragma unroll
                 for (int j = 0; j < MP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int kk = 0; kk < ksteps; ++kk, ++u) {
-                // stage of this step landed (this wave's DMAs), then everybody's; the barrier also says every wave
-                // is done reading the previous stage, whose ring slot the next DMA overwrites.  The last step of the
-                // first source also waits for the tile's side loads (parameters visible to all waves after its barrier).
-                int c = 8 + x1 + x2 + x3;
-                if (k > 0 && u == ksteps - 1) {
-                    const int cb = e1_bound + 4 * u;
-                    c = c < cb ? c : cb;
-                }
-                wait_vm(c);
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                x3 = x2;
-                x2 = x1;
-                x1 = 0;
-                const unsigned char* As = ring + ((c_slot + NS - DEPTH) & (NS - 1)) * STAGE;
-                const unsigned char* Ws = As + BP * 128;
-                issue();
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int fo = ks ? frag_off1 : frag_off0;
-                    bf16x8 af[MP], wf[MQ];
-#pragma unroll
-                    for (int j = 0; j < MP; ++j)
-                        af[j] = *reinterpret_cast<const bf16x8*>(As + (wp * TP + j * 16) * 128 + fo);
-#pragma unroll
-                    for (int i = 0; i < MQ; ++i)
-                        wf[i] = *reinterpret_cast<const bf16x8*>(Ws + (wq * TQ + i * 16) * 128 + fo);
-#pragma unroll
-                    for (int i = 0; i < MQ; ++i)
-#pragma unroll
-                        for (int j = 0; j < MP; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-                }
-            }
-            if (s == 0) {
-                // the reference loads have landed (waited for above); from here on their registers are ordinary values
-                asm volatile("" : "+v"(rfm[0][0]), "+v"(rfm[0][1]), "+v"(rfm[0][2]), "+v"(rfm[0][3]),
-                                  "+v"(rfm[1][0]), "+v"(rfm[1][1]), "+v"(rfm[1][2]), "+v"(rfm[1][3]));
-            }
+        };
+        // the reference loads have landed (waited for in the first source's last step); from here on their registers
+        // are ordinary values
+        auto tie_ref = [&]() {
+            asm volatile("" : "+v"(rfm[0][0]), "+v"(rfm[0][1]), "+v"(rfm[0][2]), "+v"(rfm[0][3]),
+                              "+v"(rfm[1][0]), "+v"(rfm[1][1]), "+v"(rfm[1][2]), "+v"(rfm[1][3]));
+        };
+        // a finished product leaves the MFMA accumulators; rows past the last pixel were computed from a repeated row
+        // and must not reach the sums
+        auto take = [&](f32x4 (&dst)[MQ][MP], const f32x4 (&acc)[MQ][MP]) {
             if (ptail) {
-                // rows past the last pixel were computed from a repeated row: they must not reach the sums
 #pragma unroll
                 for (int j = 0; j < MP; ++j) {
                     const bool pok = p_base + wp * TP + j * 16 + fr < M;
 #pragma unroll
                     for (int i = 0; i < MQ; ++i)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[i][j][e] = pok ? acc[i][j][e] : 0.f;
+                        for (int e = 0; e < 4; ++e) dst[i][j][e] = pok ? acc[i][j][e] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MQ; ++i)
+#pragma unroll
+                    for (int j = 0; j < MP; ++j) dst[i][j] = acc[i][j];
+            }
+        };
+        // ---- a source's product: ReLU mask, BatchNorm-backward sums, scaled add into the total (fragment row i).
+        //      Channels past cout carry finite garbage through their own columns only; nothing of them is stored.
+        // The sums are sum(v) and sum(v * xhat), xhat = (ref - mean) * rstd: the second one is accumulated against the
+        // raw reference value and corrected per channel afterwards, rstd * (sum(v * ref) - mean * sum(v)).
+        auto epi_main = [&](const int i, const int sp, const f32x4 (&acc)[MQ][MP], f32x4 (&s1)[MQ], f32x4 (&s2)[MQ]) {
+            const int cl = wq * TQ + i * 16 + fc * 4;
+            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(par + sp * BQ + cl);
+            const f32x4 sh4 = *reinterpret_cast<const f32x4*>(par + (4 + sp) * BQ + cl);
+            s1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            s2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < MP; ++j) {
+                const u32x2 rr = rfm[i][j];
+                const float rf[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pre = fmaf(rf[e], sc4[e], sh4[e]);
+                    const float v = pre > 0.f ? acc[i][j][e] : 0.f;
+                    s1[i][e] += v;
+                    s2[i][e] = fmaf(v, rf[e], s2[i][e]);
+                    tot[i][j][e] = fmaf(v, sc4[e], tot[i][j][e]);
                 }
             }
-            // ---- this source's product: ReLU mask, BatchNorm-backward sums, scaled add into the total.
-            //      Channels past cout carry finite garbage through their own columns only; nothing of them is stored.
-            // The sums are sum(v) and sum(v * xhat), xhat = (ref - mean) * rstd: the second one is accumulated against the
-            // raw reference value and corrected per channel afterwards, rstd * (sum(v * ref) - mean * sum(v)).
-            const bool want_s = a.sa[s] != nullptr;
-            f32x4 s1[MQ], s2[MQ];
+        };
+        auto epi_reduce = [&](const int sp, f32x4 (&s1)[MQ], f32x4 (&s2)[MQ]) {
 #pragma unroll
             for (int i = 0; i < MQ; ++i) {
                 const int cl = wq * TQ + i * 16 + fc * 4;
-                const f32x4 sc4 = *reinterpret_cast<const f32x4*>(par + s * BQ + cl);
-                const f32x4 sh4 = *reinterpret_cast<const f32x4*>(par + (4 + s) * BQ + cl);
+                const f32x4 mu4 = *reinterpret_cast<const f32x4*>(par + 8 * BQ + cl);
+                const f32x4 rs4 = *reinterpret_cast<const f32x4*>(par + 9 * BQ + cl);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s1[i][e] = 0.f, s2[i][e] = 0.f;
-#pragma unroll
-                for (int j = 0; j < MP; ++j) {
-                    const u32x2 rr = rfm[i][j];
-                    const float rf[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float pre = fmaf(rf[e], sc4[e], sh4[e]);
-                        const float v = pre > 0.f ? acc[i][j][e] : 0.f;
-                        s1[i][e] += v;
-                        s2[i][e] = fmaf(v, rf[e], s2[i][e]);
-                        tot[i][j][e] = fmaf(v, sc4[e], tot[i][j][e]);
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    s2[i][e] = rs4[e] * fmaf(-mu4[e], s1[i][e], s2[i][e]);
+                    s1[i][e] = row16_sum(s1[i][e]);
+                    s2[i][e] = row16_sum(s2[i][e]);
                 }
             }
-            if (want_s) {
+            // every lane of a row now holds all 16 totals of its four channels x two fragments x two sums: lane fr keeps
+            // total number fr (bit 3: fragment, bit 2: which sum, bits 1..0: channel) and stores it into the wave's own
+            // slots of the table (plain store: nobody else writes them; LDS float atomics cost as much per lane as
+            // sixteen four-lane instructions did)
+            float t2[MQ][2];
 #pragma unroll
-                for (int i = 0; i < MQ; ++i) {
-                    const int cl = wq * TQ + i * 16 + fc * 4;
-                    const f32x4 mu4 = *reinterpret_cast<const f32x4*>(par + 8 * BQ + cl);
-                    const f32x4 rs4 = *reinterpret_cast<const f32x4*>(par + 9 * BQ + cl);
+            for (int i = 0; i < MQ; ++i) {
+                const float p0 = s1[i][0], p1 = s1[i][1], p2 = s1[i][2], p3 = s1[i][3];
+                const float r0 = s2[i][0], r1 = s2[i][1], r2 = s2[i][2], r3 = s2[i][3];
+                const float a0 = b0 ? p1 : p0, a1 = b0 ? p3 : p2;
+                const float c0 = b0 ? r1 : r0, c1 = b0 ? r3 : r2;
+                t2[i][0] = b1 ? a1 : a0;
+                t2[i][1] = b1 ? c1 : c0;
+            }
+            const float u0 = b2 ? t2[0][1] : t2[0][0], u1 = b2 ? t2[1][1] : t2[1][0];
+            sred[(wp * 4 + sp) * 2 * BQ + sred_lane] = b3 ? u1 : u0;
+        };
+
+        f32x4 acc[MQ][MP], prod[MQ][MP];
+        f32x4 s1[MQ], s2[MQ];
+        if constexpr (KS > 0) {
+            // Overlapped form (KS K-steps per source, known at compile time): the product of source s-1 is masked, summed and
+            // added while the MFMAs of source s run -- the same wave issues both, so its vector ALU work hides behind its
+            // matrix work; every wave of the block being in the same phase, nothing else would.
+            zero(acc);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        s2[i][e] = rs4[e] * fmaf(-mu4[e], s1[i][e], s2[i][e]);
-                        s1[i][e] = row16_sum(s1[i][e]);
-                        s2[i][e] = row16_sum(s2[i][e]);
-                    }
+            for (int kk = 0; kk < KS; ++kk) kstep(acc);
+            tie_ref();
+            for (int s = 1; s < nsrc; ++s) {
+                take(prod, acc);
+                zero(acc);
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    // The step's MFMAs are issued first; the matrix pipe works through them while the same wave masks, sums
+                    // and adds the previous source's product.  (Measured: MFMAs first on every wave 2345 us; the two waves of
+                    // a SIMD in opposite orders 2497-2600; the epilogue after the source's last step, no overlap, 2439.)
+                    kstep_head();
+                    kstep_mma(acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kk == 0) epi_main(0, s - 1, prod, s1, s2);
+                    if (kk == 1) epi_main(1, s - 1, prod, s1, s2);
+                    if (kk == KS - 1) epi_reduce(s - 1, s1, s2);
                 }
-                // every lane of a row now holds all 16 totals of its four channels x two fragments x two sums: lane fr keeps
-                // total number fr (bit 3: fragment, bit 2: which sum, bits 1..0: channel) and stores it into the wave's own
-                // slots of the table (plain store: nobody else writes them; LDS float atomics cost as much per lane as
-                // sixteen four-lane instructions did)
-                float t2[MQ][2];
-#pragma unroll
-                for (int i = 0; i < MQ; ++i) {
-                    const float p0 = s1[i][0], p1 = s1[i][1], p2 = s1[i][2], p3 = s1[i][3];
-                    const float r0 = s2[i][0], r1 = s2[i][1], r2 = s2[i][2], r3 = s2[i][3];
-                    const float a0 = b0 ? p1 : p0, a1 = b0 ? p3 : p2;
-                    const float c0 = b0 ? r1 : r0, c1 = b0 ? r3 : r2;
-                    t2[i][0] = b1 ? a1 : a0;
-                    t2[i][1] = b1 ? c1 : c0;
+            }
+            take(prod, acc);
+            if (ACCG) {
+                issue_gold(p_base, q_base);
+                x1 += N_G;
+            }
+            epi_main(0, nsrc - 1, prod, s1, s2);
+            epi_main(1, nsrc - 1, prod, s1, s2);
+            epi_reduce(nsrc - 1, s1, s2);
+        } else {
+            for (int s = 0; s < nsrc; ++s) {
+                zero(acc);
+                for (int kk = 0; kk < ksteps; ++kk) kstep(acc);
+                if (s == 0) tie_ref();
+                take(prod, acc);
+                if (ACCG && s == nsrc - 1) {
+                    issue_gold(p_base, q_base);
+                    x1 += N_G;
                 }
-                const float u0 = b2 ? t2[0][1] : t2[0][0], u1 = b2 ? t2[1][1] : t2[1][0];
-                sred[(wp * 4 + s) * 2 * BQ + sred_lane] = b3 ? u1 : u0;
+                epi_main(0, s, prod, s1, s2);
+                epi_main(1, s, prod, s1, s2);
+                epi_reduce(s, s1, s2);
             }
         }
 
@@ -417,9 +481,9 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
         }
 
         // ---- slab read-modify-write through the wave-private patch, 16 pixels at a time.  The old values were
-        //      requested a whole tile ago; everything younger than them may stay outstanding.
+        //      requested before the last source's sums; only the next tile's side loads are younger.
         if (ACCG) {
-            wait_vm((T >= 2 ? 8 : 4) + (has_next ? N_PAR + N_REF : 0));
+            wait_vm(has_next ? N_PAR + N_REF : 0);
             asm volatile("" : "+v"(gold[0][0]), "+v"(gold[0][1]), "+v"(gold[1][0]), "+v"(gold[1][1]),
                               "+v"(gold[2][0]), "+v"(gold[2][1]), "+v"(gold[3][0]), "+v"(gold[3][1]));
         }
@@ -461,10 +525,9 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
                 }
             }
         }
-        if (has_next && ACCG) issue_gold(pb_n, qb_n);
         // what this tile end certainly issued after the last step's DMA, and how much of it is younger than the side loads
-        e1_bound = (full ? N_G : 0) + NE2;
-        x1 = has_next ? N_PAR + N_REF + e1_bound : 0;
+        e1_bound = full ? N_G : 0;
+        x1 += has_next ? N_PAR + N_REF + e1_bound : 0;
     }
     // nothing of this block may land in LDS after it has gone
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -520,10 +583,12 @@ int dsaspp_dgrad_group_launch(const dsaspp_conv_desc& d, hipStream_t s) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
             n_cu = 256;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_group_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_group_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_group_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_group_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        const void* kernels[] = {
+            (const void*)dgrad_group_kernel<false, false, 0>, (const void*)dgrad_group_kernel<false, true, 0>, (const void*)dgrad_group_kernel<true, false, 0>,
+            (const void*)dgrad_group_kernel<true, true, 0>,   (const void*)dgrad_group_kernel<false, false, 2>, (const void*)dgrad_group_kernel<false, true, 2>,
+            (const void*)dgrad_group_kernel<true, false, 2>,  (const void*)dgrad_group_kernel<true, true, 2>,   (const void*)dgrad_group_kernel<false, false, 3>,
+            (const void*)dgrad_group_kernel<false, true, 3>,  (const void*)dgrad_group_kernel<true, false, 3>,  (const void*)dgrad_group_kernel<true, true, 3>};
+        for (const void* f : kernels) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     }
     int64_t tiles = (int64_t)a.nP * a.nQ;
     int grid = (int)((tiles + 7) / 8 * 8);
@@ -534,8 +599,17 @@ int dsaspp_dgrad_group_launch(const dsaspp_conv_desc& d, hipStream_t s) {
     }
     if (grid > cap) grid = cap;
     if (grid < 8) grid = 8;
-    auto kern = d.g_accumulate ? (d.g_bf16 ? dgrad_group_kernel<true, true> : dgrad_group_kernel<true, false>)
-                               : (d.g_bf16 ? dgrad_group_kernel<false, true> : dgrad_group_kernel<false, false>);
+    // K-steps per source: 2 and 3 (bottleneck widths 128 and 192) have the overlapped form
+    const int ks = d.cin / BK;
+    const bool no_overlap = getenv("DSASPP_DGG_NO_OVERLAP") != nullptr;      // A/B measurement hook
+    void (*kern)(const GArgs);
+#define DGG_PICK(KS_)                                                                                              \
+    kern = d.g_accumulate ? (d.g_bf16 ? dgrad_group_kernel<true, true, KS_> : dgrad_group_kernel<true, false, KS_>) \
+                          : (d.g_bf16 ? dgrad_group_kernel<false, true, KS_> : dgrad_group_kernel<false, false, KS_>)
+    if (ks == 3 && !no_overlap) DGG_PICK(3);
+    else if (ks == 2 && !no_overlap) DGG_PICK(2);
+    else DGG_PICK(0);
+#undef DGG_PICK
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), LDS_BYTES, s, a);
     DS_LAUNCH_CHECK("conv_fwd(grouped data gradient)");
     return 0;
