@@ -715,7 +715,11 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
         const int rc = dsaspp_dgrad_group_launch(d, s);
         return rc >= 0 ? rc : launch_multi(d, s);
     }
-    if (d.g && d.cout >= 192) {   // wide slab data gradients of the masked form: persistent DMA-fed kernel
+    // slab data gradients of the masked form: persistent DMA-fed kernel.  The narrow ones too (48..144 channels a group of
+    // dense layers produced itself): they are bound by the slab traffic, which that kernel keeps in flight across tiles
+    // (DSASPP_DGG_MIN_COUT overrides the threshold for A/B measurements).
+    static const int dgg_min_cout = [] { const char* e = getenv("DSASPP_DGG_MIN_COUT"); return e ? atoi(e) : 48; }();
+    if (d.g && d.cout >= dgg_min_cout) {
         const int rc = dsaspp_dgrad_group_launch(d, s);
         if (rc >= 0) return rc;
     }

@@ -31,6 +31,11 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef DGG_ABL
+#define DGG_ABL 0     // diagnostic builds (timing only, results wrong): 1 no fragment reads / MFMA, 2 no per-source mask / sums, 3 no operand DMA,
+                      // 4 no side loads and no slab stores, 5 no cross-lane reduction of the sums, 6 no per-step barrier
+#endif
+
 namespace {
 
 constexpr int BP = 128, BQ = 128, BK = 64;
@@ -106,7 +111,9 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cin = a.cin, cout = a.cout, M = a.M, nQ = a.nQ;
-    const int ksteps = cin / BK;
+    const int ksteps = (cin + BK - 1) / BK;
+    const int rem = cin - (ksteps - 1) * BK;         // channels of a source's last K-step (a multiple of 8)
+    const bool has_tail = rem < BK;
     const int nsrc = a.nsrc;
 
     // ---- this block's tile sequence: XCD x = blockIdx % 8 owns the pixel tiles pt = x (mod 8)
@@ -127,6 +134,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
     const int drow = lane >> 3, dchunk = lane & 7;
     int c_k = 0, c_s = 0, c_kk = 0, c_slot = 0;
     uint32_t a_off[2], w_off[2];                     // byte offsets of this lane's two rows
+    const uint32_t lcb = (uint32_t)((dchunk ^ swz8(wave * 8 + drow)) * 16);      // this lane's (swizzled) chunk inside the 128-byte K window
     const u16* cur_x = a.x[0];
     const u16* cur_w = a.w[0];
     auto cursor_tile = [&]() {
@@ -149,14 +157,26 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
     auto issue = [&]() {
         const uint32_t slot_l = ring_l + c_slot * STAGE;
         const uint32_t kb = c_kk * (BK * 2);
+        uint32_t ao[2] = {a_off[0] + kb, a_off[1] + kb}, wo[2] = {w_off[0] + kb, w_off[1] + kb};
+        if (has_tail && c_kk == ksteps - 1 && kb + lcb >= (uint32_t)cin * 2u) {
+            // a chunk past the last channel: fetch the row's first chunk instead (finite values of the same tensor);
+            // the step's MFMAs see zeros in its place
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ao[i] = a_off[i] - lcb;
+                wo[i] = w_off[i] - lcb;
+            }
+        }
+        if (DGG_ABL != 3)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         : : "s"(slot_l + (i * 8 + wave) * 1024), "v"(a_off[i] + kb), "s"(cur_x) : "memory");
+                         : : "s"(slot_l + (i * 8 + wave) * 1024), "v"(ao[i]), "s"(cur_x) : "memory");
+        if (DGG_ABL != 3)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         : : "s"(slot_l + BP * 128 + (i * 8 + wave) * 1024), "v"(w_off[i] + kb), "s"(cur_w) : "memory");
+                         : : "s"(slot_l + BP * 128 + (i * 8 + wave) * 1024), "v"(wo[i]), "s"(cur_w) : "memory");
         c_slot = (c_slot + 1) & (NS - 1);
         if (c_k < ntile) {
             if (++c_kk == ksteps) {
@@ -287,7 +307,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
                 c = c < cb ? c : cb;
             }
             wait_vm(c);
-            __builtin_amdgcn_s_barrier();
+            if (DGG_ABL != 6) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             x3 = x2;
             x2 = x1;
@@ -296,10 +316,10 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
             As = ring + ((c_slot + NS - DEPTH) & (NS - 1)) * STAGE;
             issue();
         };
-        auto kstep_mma = [&](f32x4 (&acc)[MQ][MP]) {
+        auto kstep_mma = [&](f32x4 (&acc)[MQ][MP], const bool tail) {
             const unsigned char* Ws = As + BP * 128;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < (DGG_ABL == 1 ? 0 : 2); ++ks) {
                 const int fo = ks ? frag_off1 : frag_off0;
                 bf16x8 af[MP], wf[MQ];
 #pragma unroll
@@ -308,18 +328,21 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
 #pragma unroll
                 for (int i = 0; i < MQ; ++i)
                     wf[i] = *reinterpret_cast<const bf16x8*>(Ws + (wq * TQ + i * 16) * 128 + fo);
+                if (tail && ks * 32 + fc * 8 >= rem) {
+                    // this lane's 8 channels of the pixel operand lie past the last channel
+#pragma unroll
+                    for (int j = 0; j < MP; ++j) af[j] = bf16x8{};
+                }
 #pragma unroll
                 for (int i = 0; i < MQ; ++i)
 #pragma unroll
                     for (int j = 0; j < MP; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-                if (KS > 0 && ks == 0) __builtin_amdgcn_sched_barrier(0x008);      // only MFMAs may cross: the second half's fragments are
-                                                                                 // not fetched into registers the first half still needs
             }
         };
-        auto kstep = [&](f32x4 (&acc)[MQ][MP]) {
+        auto kstep = [&](f32x4 (&acc)[MQ][MP], const bool tail) {
             kstep_head();
-            kstep_mma(acc);
+            kstep_mma(acc, tail);
         };
         auto zero = [&](f32x4 (&acc)[MQ][MP]) {
 #pragma unroll
@@ -362,6 +385,11 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
             const f32x4 sh4 = *reinterpret_cast<const f32x4*>(par + (4 + sp) * BQ + cl);
             s1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             s2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (DGG_ABL == 2) {
+#pragma unroll
+                for (int j = 0; j < MP; ++j) tot[i][j] += acc[i][j];
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < MP; ++j) {
                 const u32x2 rr = rfm[i][j];
@@ -377,6 +405,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
             }
         };
         auto epi_reduce = [&](const int sp, f32x4 (&s1)[MQ], f32x4 (&s2)[MQ]) {
+            if (DGG_ABL == 2) return;
 #pragma unroll
             for (int i = 0; i < MQ; ++i) {
                 const int cl = wq * TQ + i * 16 + fc * 4;
@@ -385,8 +414,10 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     s2[i][e] = rs4[e] * fmaf(-mu4[e], s1[i][e], s2[i][e]);
-                    s1[i][e] = row16_sum(s1[i][e]);
-                    s2[i][e] = row16_sum(s2[i][e]);
+                    if (DGG_ABL != 5) {
+                        s1[i][e] = row16_sum(s1[i][e]);
+                        s2[i][e] = row16_sum(s2[i][e]);
+                    }
                 }
             }
             // every lane of a row now holds all 16 totals of its four channels x two fragments x two sums: lane fr keeps
@@ -415,7 +446,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
             // matrix work; every wave of the block being in the same phase, nothing else would.
             zero(acc);
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) kstep(acc);
+            for (int kk = 0; kk < KS; ++kk) kstep(acc, false);
             tie_ref();
             for (int s = 1; s < nsrc; ++s) {
                 take(prod, acc);
@@ -426,7 +457,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
                     // and adds the previous source's product.  (Measured: MFMAs first on every wave 2345 us; the two waves of
                     // a SIMD in opposite orders 2497-2600; the epilogue after the source's last step, no overlap, 2439.)
                     kstep_head();
-                    kstep_mma(acc);
+                    kstep_mma(acc, false);
                     __builtin_amdgcn_sched_barrier(0);
                     if (kk == 0) epi_main(0, s - 1, prod, s1, s2);
                     if (kk == 1) epi_main(1, s - 1, prod, s1, s2);
@@ -435,7 +466,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
             }
             take(prod, acc);
             if (ACCG) {
-                issue_gold(p_base, q_base);
+                if (DGG_ABL != 4) issue_gold(p_base, q_base);
                 x1 += N_G;
             }
             epi_main(0, nsrc - 1, prod, s1, s2);
@@ -444,7 +475,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
         } else {
             for (int s = 0; s < nsrc; ++s) {
                 zero(acc);
-                for (int kk = 0; kk < ksteps; ++kk) kstep(acc);
+                for (int kk = 0; kk < ksteps; ++kk) kstep(acc, has_tail && kk == ksteps - 1);
                 if (s == 0) tie_ref();
                 take(prod, acc);
                 if (ACCG && s == nsrc - 1) {
@@ -476,8 +507,10 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
         int pb_n = 0, qb_n = 0;
         if (has_next) {
             tile_coords(k + 1, pb_n, qb_n);
-            issue_par(qb_n);
-            issue_ref(pb_n, qb_n);
+            if (DGG_ABL != 4) {
+                issue_par(qb_n);
+                issue_ref(pb_n, qb_n);
+            }
         }
 
         // ---- slab read-modify-write through the wave-private patch, 16 pixels at a time.  The old values were
@@ -507,6 +540,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
                     }
                 }
                 const uint32_t off = slab_off(p_base, q_base, j, rp);
+                if (DGG_ABL == 4 && a4[0] != 12345.678f) continue;
                 if constexpr (GBF16) {
                     u32x2 o;
                     o.x = pack_bf2(t[0], t[1]);
@@ -528,6 +562,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
         // what this tile end certainly issued after the last step's DMA, and how much of it is younger than the side loads
         e1_bound = full ? N_G : 0;
         x1 += has_next ? N_PAR + N_REF + e1_bound : 0;
+        if (DGG_ABL == 4) x1 = 0, e1_bound = 0;
     }
     // nothing of this block may land in LDS after it has gone
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -539,7 +574,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
 // then uses the general convolution kernel), 0 on success, a positive error code otherwise.
 int dsaspp_dgrad_group_launch(const dsaspp_conv_desc& d, hipStream_t s) {
     const bool form = d.g && d.taps == 1 && d.epi_relu == 1 && d.ref && d.e_scale && d.e_shift && d.e_mean && d.e_rstd && !d.in_scale &&
-                      !d.in_mask && !d.in_relu && !d.bias && !d.out_mask && d.cin % BK == 0 && d.cin <= 1024 && d.cout >= 4 &&
+                      !d.in_mask && !d.in_relu && !d.bias && !d.out_mask && d.cin % 8 == 0 && d.cin >= BK && d.cin <= 4096 && d.ldx % 8 == 0 && d.cout >= 4 &&
                       d.cout % 4 == 0 && d.n_src <= 4;
     if (!form) return -1;
     const int64_t M64 = (int64_t)d.n_img * d.H * d.W;
@@ -600,7 +635,7 @@ int dsaspp_dgrad_group_launch(const dsaspp_conv_desc& d, hipStream_t s) {
     if (grid > cap) grid = cap;
     if (grid < 8) grid = 8;
     // K-steps per source: 2 and 3 (bottleneck widths 128 and 192) have the overlapped form
-    const int ks = d.cin / BK;
+    const int ks = d.cin % BK == 0 ? d.cin / BK : 0;
     const bool no_overlap = getenv("DSASPP_DGG_NO_OVERLAP") != nullptr;      // A/B measurement hook
     void (*kern)(const GArgs);
 #define DGG_PICK(KS_)                                                                                              \

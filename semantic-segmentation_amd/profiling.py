@@ -6,6 +6,7 @@ profiler shows.  Algorithmic work: 2*M*cout*taps*cin flops for a convolution or 
 launch; bytes for the fused upsample + cross-entropy kernel (low-res logits read + labels read +
 low-res gradient written).
 """
+import os
 
 CLASSES = ['untimed',
            'conv_kernel<128,192,2,4>', 'conv_kernel<128,128,2,4>', 'conv_kernel<256,48,4,1>',
@@ -19,10 +20,10 @@ def kernel_class(kind, f):
     if kind == 'conv':
         co = f['cout']
         if (f.get('n_src') or 0) > 1 or (
-                f.get('g') is not None and co >= 192 and f['taps'] == 1 and f.get('epi_relu') and f.get('ref') is not None
+                f.get('g') is not None and co >= int(os.environ.get('DSASPP_DGG_MIN_COUT', 48)) and f['taps'] == 1 and f.get('epi_relu') and f.get('ref') is not None
                 and f.get('e_scale') is not None and f.get('e_mean') is not None and f.get('in_scale') is None
                 and f.get('in_mask') is None and not f.get('in_relu') and f.get('bias') is None and f.get('out_mask') is None
-                and f['cin'] % 64 == 0 and f['cin'] <= 1024):
+                and f.get('epi_relu') == 1 and f['cin'] % 8 == 0 and 64 <= f['cin'] <= 4096 and f['ldx'] % 8 == 0 and co % 4 == 0):
             return 12
         if (f['taps'] == 9 and 1 <= f['dil'] <= 4 and co <= 64 and f['cin'] % 64 == 0 and f.get('g') is None
                 and not f.get('epi_relu') and f.get('s_acc') is None and not f.get('y_f32') and f.get('in_mask') is None

@@ -144,7 +144,9 @@ def test_conv_multi_source(n_src):
 
 @pytest.mark.parametrize('n_src,cin,g_bf16,g_acc,stats', [
     (4, 192, True, True, True), (4, 192, False, True, True), (3, 192, True, False, True), (2, 128, True, True, True),
-    (1, 128, False, True, True), (1, 64, True, True, True), (2, 64, True, True, False), (4, 320, True, True, True)])
+    (1, 128, False, True, True), (1, 64, True, True, True), (2, 64, True, True, False), (4, 320, True, True, True),
+    # bottleneck widths that are not a multiple of the 64-channel K-step (the transitions' data gradients: 1056, 1104)
+    (1, 208, True, False, True), (2, 224, True, True, True), (1, 240, False, True, True), (1, 1104, True, False, True)])
 def test_dgrad_group_many_tiles(n_src, cin, g_bf16, g_acc, stats, monkeypatch):
     """The persistent grouped data-gradient kernel with eight blocks only, so that every block walks several
     (pixel tile, channel tile) pairs: the side loads of tile k+1 are requested while tile k finishes, and the
