@@ -222,6 +222,41 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const dsaspp_bnapply_desc
     if (d.colsum) block_colsum<CGB, 1>(part, red, d.colsum, d.C, blockIdx.x * CGB, 0, 0);
 }
 
+// Contiguous form (all three tensors [M][C] with no padding, no column sums): the tensors are one long array of 16-byte
+// chunks.  The grid stride is a multiple of the chunks per row, so a thread keeps its channel group (coefficients loaded
+// once) and every lane is busy whatever C is (192 channels are 24 chunks: the row-block form leaves 8 of 32 lanes idle).
+template <bool DRF32>
+__global__ __launch_bounds__(256) void bn_apply_flat_kernel(const dsaspp_bnapply_desc d, const int CG, const int64_t nchunks) {
+    const int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    const int c = (int)(g0 % CG) * 8;
+    float A[8], B[8], Cc[8];
+    load8f(d.coefA + c, A); load8f(d.coefB + c, B); load8f(d.coefC + c, Cc);
+    const uint4* yy = reinterpret_cast<const uint4*>(d.y);
+    uint4* dy = reinterpret_cast<uint4*>(d.dy);
+    constexpr int U = 4;
+    for (int64_t g = g0; g < nchunks; g += U * stride) {
+        float a[U][8];
+        uint4 yv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t gu = g + u * stride;
+            const int64_t gc = gu < nchunks ? gu : g;
+            if (DRF32) load8f(reinterpret_cast<const float*>(d.dr) + gc * 8, a[u]);
+            else unpack8(reinterpret_cast<const uint4*>(d.dr)[gc], a[u]);
+            yv[u] = yy[gc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t gu = g + u * stride;
+            float y[8], o[8];
+            unpack8(yv[u], y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(A[e], a[u][e], fmaf(B[e], y[e], Cc[e]));
+            if (gu < nchunks) dy[gu] = pack8(o);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- 2x2 average pooling
 template <int CGB>
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const dsaspp_pool_desc d) {
@@ -452,6 +487,8 @@ inline dim3 row_grid(int C, int64_t M, int cgb) {
     do {                                                                                    \
         if ((C) <= 64) {                                                                    \
             hipLaunchKernelGGL(KERN<8>, row_grid((C), (M), 8), dim3(256), 0, s, desc);      \
+        } else if ((C) <= 128) { /* 96 channels: 12 of 16 lanes busy instead of 12 of 32 */ \
+            hipLaunchKernelGGL(KERN<16>, row_grid((C), (M), 16), dim3(256), 0, s, desc);    \
         } else {                                                                            \
             hipLaunchKernelGGL(KERN<32>, row_grid((C), (M), 32), dim3(256), 0, s, desc);    \
         }                                                                                   \
@@ -504,6 +541,21 @@ extern "C" int dsaspp_grad_extract(const dsaspp_gradx_desc* d, dsaspp_stream_t s
 extern "C" int dsaspp_bn_bwd_apply(const dsaspp_bnapply_desc* d, dsaspp_stream_t stream) {
     DS_REQUIRE(d && d->M > 0 && d->C > 0 && d->C % 8 == 0 && d->lddr % 8 == 0 && d->ldy % 8 == 0 && d->lddy % 8 == 0, "bn_bwd_apply: bad descriptor");
     DS_REQUIRE(d->dr && d->y && d->dy && d->coefA && d->coefB && d->coefC, "bn_bwd_apply: null tensor");
+    if (!d->colsum && d->lddr == d->C && d->ldy == d->C && d->lddy == d->C &&
+        (((uintptr_t)d->dr | (uintptr_t)d->y | (uintptr_t)d->dy) & 15) == 0) {
+        const int CG = d->C / 8;
+        int q = CG, r = 256;                      // q = CG / gcd(256, CG): grid sizes that keep a thread on one channel group
+        while (r) { const int t = q % r; q = r; r = t; }
+        q = CG / q;
+        const int64_t nchunks = d->M * CG;
+        int64_t blocks = (nchunks + 4 * 256 - 1) / (4 * 256);
+        if (blocks > 2048) blocks = 2048;
+        blocks = (blocks + q - 1) / q * q;
+        if (d->dr_f32) hipLaunchKernelGGL(bn_apply_flat_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d, CG, nchunks);
+        else hipLaunchKernelGGL(bn_apply_flat_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d, CG, nchunks);
+        DS_LAUNCH_CHECK("bn_bwd_apply");
+        return 0;
+    }
     ROW_DISPATCH(bn_apply_kernel, d->C, d->M, *d, (hipStream_t)stream);
     DS_LAUNCH_CHECK("bn_bwd_apply");
     return 0;
