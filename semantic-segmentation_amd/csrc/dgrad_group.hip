@@ -50,6 +50,7 @@ constexpr int PAR_BYTES = PAR_ROWS * BQ * 4;
 constexpr int SRED_BYTES = WP * 4 * 2 * BQ * 4;                        // [pixel half of the tile][source][which sum][channel]
 constexpr int LDS_BYTES = NS * STAGE + PATCH_BYTES + PAR_BYTES + SRED_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(16 * 72 <= 16 * ROWF * 4, "reference patch");
 static_assert(MQ == 2 && MP == 4, "register tie statements are written for a 64 x 32 wave tile");
 constexpr int N_PAR = 3;                  // parameter DMAs per wave and tile (20 half rows over 8 waves, padded)
 constexpr int N_REF = MQ * MP;            // reference loads per wave and tile
@@ -228,19 +229,22 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(par_l + idx * 256), "v"(src) : "memory");
         }
     };
-    u32x2 rfm[MQ][MP];
+    // Reference activations of a tile.  They are fetched in the row layout of the slab read-modify-write (8 lanes cover 64
+    // contiguous bytes of a pixel; in accumulator layout a load instruction touches 16 rows for 32 bytes each and the
+    // tile's eight loads cost 11 % of the kernel) and reach the accumulator layout through the wave's LDS patch.
+    u32x2 rfm[MQ][MP], rfp[MP][NRP];
     auto issue_ref = [&](int pb, int qb) {
         const u16* base = a.ref + (int64_t)pb * a.ldref;
 #pragma unroll
-        for (int i = 0; i < MQ; ++i)
+        for (int j = 0; j < MP; ++j)
 #pragma unroll
-            for (int j = 0; j < MP; ++j) {
-                int p = pb + wp * TP + j * 16 + fr;
+            for (int rp = 0; rp < NRP; ++rp) {
+                int p = pb + wp * TP + j * 16 + rp * RPP + er;
                 p = (p < M ? p : M - 1) - pb;
-                int q = qb + wq * TQ + i * 16 + fc * 4;
+                int q = qb + wq * TQ + ec * 4;
                 q = q < cout - 4 ? q : cout - 4;
                 const uint32_t off = ((uint32_t)p * (uint32_t)a.ldref + q) * 2u;
-                asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(rfm[i][j]) : "v"(off), "s"(base) : "memory");
+                asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(rfp[j][rp]) : "v"(off), "s"(base) : "memory");
             }
     };
     gvec_t gold[MP][NRP];
@@ -353,8 +357,19 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
         // the reference loads have landed (waited for in the first source's last step); from here on their registers
         // are ordinary values
         auto tie_ref = [&]() {
-            asm volatile("" : "+v"(rfm[0][0]), "+v"(rfm[0][1]), "+v"(rfm[0][2]), "+v"(rfm[0][3]),
-                              "+v"(rfm[1][0]), "+v"(rfm[1][1]), "+v"(rfm[1][2]), "+v"(rfm[1][3]));
+            asm volatile("" : "+v"(rfp[0][0]), "+v"(rfp[0][1]), "+v"(rfp[1][0]), "+v"(rfp[1][1]),
+                              "+v"(rfp[2][0]), "+v"(rfp[2][1]), "+v"(rfp[3][0]), "+v"(rfp[3][1]));
+            unsigned char* st = reinterpret_cast<unsigned char*>(stage);      // 16 rows x 32 bf16, 72-byte rows
+#pragma unroll
+            for (int j = 0; j < MP; ++j) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int rp = 0; rp < NRP; ++rp) *reinterpret_cast<u32x2*>(st + (rp * RPP + er) * 72 + ec * 8) = rfp[j][rp];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < MQ; ++i) rfm[i][j] = *reinterpret_cast<const u32x2*>(st + fr * 72 + i * 32 + fc * 8);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         // a finished product leaves the MFMA accumulators; rows past the last pixel were computed from a repeated row
         // and must not reach the sums
