@@ -33,7 +33,7 @@
 
 #ifndef DGG_ABL
 #define DGG_ABL 0     // diagnostic builds (timing only, results wrong): 1 no fragment reads / MFMA, 2 no per-source mask / sums, 3 no operand DMA,
-                      // 4 no side loads and no slab stores, 5 no cross-lane reduction of the sums, 6 no per-step barrier
+                      // 4 no side loads and no slab stores, 6 no per-step barrier
 #endif
 
 namespace {
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
     const int rep = blockIdx.x % DS_R;
     float* stage = patch + wave * (16 * ROWF);
     const int er = lane >> 3, ec = lane & 7;
-    const bool b0 = fr & 1, b1 = fr & 2, b2 = fr & 4, b3 = fr & 8;
+    const bool b0 = fr & 1, b1 = fr & 2;
     const int sred_lane = ((fr >> 2) & 1) * BQ + wq * TQ + (fr >> 3) * 16 + fc * 4 + (fr & 3);      // [which sum][channel] of the total this lane keeps
 
     // ---- per-tile side loads
@@ -421,6 +421,11 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
         };
         auto epi_reduce = [&](const int sp, f32x4 (&s1)[MQ], f32x4 (&s2)[MQ]) {
             if (DGG_ABL == 2) return;
+            // 16 partial sums per lane, V[t] with t = fragment * 8 + which sum * 4 + channel, to be added over the 16 lanes
+            // (pixels) of a DPP row.  Reduce-scatter instead of 16 full butterflies: every exchange step halves the values a
+            // lane still carries (16 + 8 + 6 + 3 vector instructions instead of 64 and a 15-select tree), and lane fr ends
+            // up with the row total of value number fr.
+            float x[8], w[8];
 #pragma unroll
             for (int i = 0; i < MQ; ++i) {
                 const int cl = wq * TQ + i * 16 + fc * 4;
@@ -428,29 +433,46 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
                 const f32x4 rs4 = *reinterpret_cast<const f32x4*>(par + 9 * BQ + cl);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    s2[i][e] = rs4[e] * fmaf(-mu4[e], s1[i][e], s2[i][e]);
-                    if (DGG_ABL != 5) {
-                        s1[i][e] = row16_sum(s1[i][e]);
-                        s2[i][e] = row16_sum(s2[i][e]);
-                    }
+                    const float c2 = rs4[e] * fmaf(-mu4[e], s1[i][e], s2[i][e]);
+                    if (i == 0) x[e] = s1[i][e], x[4 + e] = c2;
+                    else w[e] = s1[i][e], w[4 + e] = c2;
                 }
             }
-            // every lane of a row now holds all 16 totals of its four channels x two fragments x two sums: lane fr keeps
-            // total number fr (bit 3: fragment, bit 2: which sum, bits 1..0: channel) and stores it into the wave's own
-            // slots of the table (plain store: nobody else writes them; LDS float atomics cost as much per lane as
-            // sixteen four-lane instructions did)
-            float t2[MQ][2];
+            // lanes fr and fr ^ 8: lanes 0..7 of a row keep fragment 0 (x), lanes 8..15 (banks 2, 3) fragment 1 (w).
+            // (s_nop: a DPP operand must not be read within two cycles of the instruction that wrote it; the compiler does
+            // not see DPP reads inside inline assembly)
+#define DGG_RS_A(n) "v_add_f32_dpp %" #n ", %" #n ", %" #n " row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+#define DGG_RS_A2(n, m) "v_add_f32_dpp %" #n ", %" #m ", %" #m " row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            asm volatile("s_nop 1\n\t"
+                         DGG_RS_A(0) DGG_RS_A(1) DGG_RS_A(2) DGG_RS_A(3) DGG_RS_A(4) DGG_RS_A(5) DGG_RS_A(6) DGG_RS_A(7)
+                         DGG_RS_A2(0, 8) DGG_RS_A2(1, 9) DGG_RS_A2(2, 10) DGG_RS_A2(3, 11) DGG_RS_A2(4, 12) DGG_RS_A2(5, 13) DGG_RS_A2(6, 14) DGG_RS_A2(7, 15)
+                         "s_nop 1"
+                         : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+                         : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
+#undef DGG_RS_A
+#undef DGG_RS_A2
+            // lanes fr and fr ^ 4: banks 0 and 2 keep the first sum (x[0..3], partner four lanes up), banks 1 and 3 the
+            // second (x[4..7], partner four lanes down)
+            float y[4];
+#define DGG_RS_B(n, lo, hi)                                                                        \
+    "v_add_f32_dpp %" #n ", %" #lo ", %" #lo " row_shl:4 row_mask:0xf bank_mask:0x5\n\t"          \
+    "v_add_f32_dpp %" #n ", %" #hi ", %" #hi " row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            asm volatile(DGG_RS_B(0, 4, 8) DGG_RS_B(1, 5, 9) DGG_RS_B(2, 6, 10) DGG_RS_B(3, 7, 11) "s_nop 1"
+                         : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3])
+                         : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+#undef DGG_RS_B
+            // lanes fr ^ 2, then fr ^ 1, inside the quad: keep one half, send the other
+            float z[2];
 #pragma unroll
-            for (int i = 0; i < MQ; ++i) {
-                const float p0 = s1[i][0], p1 = s1[i][1], p2 = s1[i][2], p3 = s1[i][3];
-                const float r0 = s2[i][0], r1 = s2[i][1], r2 = s2[i][2], r3 = s2[i][3];
-                const float a0 = b0 ? p1 : p0, a1 = b0 ? p3 : p2;
-                const float c0 = b0 ? r1 : r0, c1 = b0 ? r3 : r2;
-                t2[i][0] = b1 ? a1 : a0;
-                t2[i][1] = b1 ? c1 : c0;
+            for (int m = 0; m < 2; ++m) {
+                const float keep = b1 ? y[2 + m] : y[m], send = b1 ? y[m] : y[2 + m];
+                z[m] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xF, 0xF, true));
             }
-            const float u0 = b2 ? t2[0][1] : t2[0][0], u1 = b2 ? t2[1][1] : t2[1][0];
-            sred[(wp * 4 + sp) * 2 * BQ + sred_lane] = b3 ? u1 : u0;
+            const float keep = b0 ? z[1] : z[0], send = b0 ? z[0] : z[1];
+            const float total = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, true));
+            // one plain store per wave and source into the wave's own slots of the table (nobody else writes them; LDS float
+            // atomics cost as much per lane as sixteen four-lane instructions did)
+            sred[(wp * 4 + sp) * 2 * BQ + sred_lane] = total;
         };
 
         f32x4 acc[MQ][MP], prod[MQ][MP];
