@@ -405,17 +405,28 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
                 for (int j = 0; j < MP; ++j) tot[i][j] += acc[i][j];
                 return;
             }
+            // ReLU mask as a number: clamp(2^64 * (ref * scale + shift)) is 1 for every positive pre-activation of at least
+            // 2^-64, 0 for zero, negatives and NaN -- one packed fma with the clamp modifier per two elements instead of a
+            // compare and a select per element (the power of two scales exactly, the sign is that of the unscaled value).
+            constexpr float BIG = 18446744073709551616.f;
+            const f32x2_t scb[2] = {{sc4[0] * BIG, sc4[1] * BIG}, {sc4[2] * BIG, sc4[3] * BIG}};
+            const f32x2_t shb[2] = {{sh4[0] * BIG, sh4[1] * BIG}, {sh4[2] * BIG, sh4[3] * BIG}};
 #pragma unroll
             for (int j = 0; j < MP; ++j) {
                 const u32x2 rr = rfm[i][j];
-                const float rf[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
+                const f32x2_t rf[2] = {{bf_lo(rr.x), bf_hi(rr.x)}, {bf_lo(rr.y), bf_hi(rr.y)}};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pre = fmaf(rf[e], sc4[e], sh4[e]);
-                    const float v = pre > 0.f ? acc[i][j][e] : 0.f;
-                    s1[i][e] += v;
-                    s2[i][e] = fmaf(v, rf[e], s2[i][e]);
-                    tot[i][j][e] = fmaf(v, sc4[e], tot[i][j][e]);
+                for (int h = 0; h < 2; ++h) {
+                    f32x2_t m;
+                    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m) : "v"(rf[h]), "v"(scb[h]), "v"(shb[h]));
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const int e = h * 2 + e2;
+                        const float v = acc[i][j][e] * m[e2];
+                        s1[i][e] += v;
+                        s2[i][e] = fmaf(v, rf[h][e2], s2[i][e]);
+                        tot[i][j][e] = fmaf(v, sc4[e], tot[i][j][e]);
+                    }
                 }
             }
         };
