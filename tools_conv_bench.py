@@ -38,6 +38,9 @@ cases = {
  'fwd3x3': conv(n_img=n, H=H, W=W, cin=192, cout=48, taps=9, dil=2, x=Ref(y1), ldx=192, w=Ref(w2), in_scale=Ref(sc2), in_shift=Ref(sh2), in_relu=1, y=Ref(slab, CIN), ldy=LD, stat_acc=Ref(acc)),
  'fwd3x3_d4': conv(n_img=n, H=H, W=W, cin=192, cout=48, taps=9, dil=4, x=Ref(y1), ldx=192, w=Ref(w2), in_scale=Ref(sc2), in_shift=Ref(sh2), in_relu=1, y=Ref(slab, CIN), ldy=LD, stat_acc=Ref(acc)),
  'dgrad3x3': conv(n_img=n, H=H, W=W, cin=48, cout=192, taps=9, dil=2, x=Ref(dz48), ldx=48, w=Ref(w2t), y=Ref(dr), ldy=192, y_f32=1, epi_relu=1, ref=Ref(y1), ldref=192, e_scale=Ref(sc2), e_shift=Ref(sh2), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc)),
+ 'dgrad3x3_noS': conv(n_img=n, H=H, W=W, cin=48, cout=192, taps=9, dil=2, x=Ref(dz48), ldx=48, w=Ref(w2t), y=Ref(dr), ldy=192, y_f32=1, epi_relu=1, ref=Ref(y1), ldref=192, e_scale=Ref(sc2), e_shift=Ref(sh2)),
+ 'dgrad3x3_plain': conv(n_img=n, H=H, W=W, cin=48, cout=192, taps=9, dil=2, x=Ref(dz48), ldx=48, w=Ref(w2t), y=Ref(dr), ldy=192, y_f32=1),
+ 'dgrad3x3_bf16': conv(n_img=n, H=H, W=W, cin=48, cout=192, taps=9, dil=2, x=Ref(dz48), ldx=48, w=Ref(w2t), y=Ref(y1b), ldy=192, y_f32=0, epi_relu=1, ref=Ref(y1), ldref=192, e_scale=Ref(sc2), e_shift=Ref(sh2), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc)),
  'dgrad1x1_slab': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc), g=Ref(g), ldg=LD, g_accumulate=1),
  'dgrad1x1_slab16': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc), g=Ref(g16), ldg=LD, g_accumulate=1, g_bf16=1),
  'slab_noS': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), g=Ref(g), ldg=LD, g_accumulate=1),
