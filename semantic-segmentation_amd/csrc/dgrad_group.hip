@@ -232,7 +232,8 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
     // Reference activations of a tile.  They are fetched in the row layout of the slab read-modify-write (8 lanes cover 64
     // contiguous bytes of a pixel; in accumulator layout a load instruction touches 16 rows for 32 bytes each and the
     // tile's eight loads cost 11 % of the kernel) and reach the accumulator layout through the wave's LDS patch.
-    u32x2 rfm[MQ][MP], rfp[MP][NRP];
+    f32x4 rfm[MQ][MP];      // unpacked to fp32 once per tile: every source's mask and second sum read them
+    u32x2 rfp[MP][NRP];
     auto issue_ref = [&](int pb, int qb) {
         const u16* base = a.ref + (int64_t)pb * a.ldref;
 #pragma unroll
@@ -367,7 +368,10 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
                 for (int rp = 0; rp < NRP; ++rp) *reinterpret_cast<u32x2*>(st + (rp * RPP + er) * 72 + ec * 8) = rfp[j][rp];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int i = 0; i < MQ; ++i) rfm[i][j] = *reinterpret_cast<const u32x2*>(st + fr * 72 + i * 32 + fc * 8);
+                for (int i = 0; i < MQ; ++i) {
+                    const u32x2 rr = *reinterpret_cast<const u32x2*>(st + fr * 72 + i * 32 + fc * 8);
+                    rfm[i][j] = f32x4{bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
@@ -413,8 +417,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
             const f32x2_t shb[2] = {{sh4[0] * BIG, sh4[1] * BIG}, {sh4[2] * BIG, sh4[3] * BIG}};
 #pragma unroll
             for (int j = 0; j < MP; ++j) {
-                const u32x2 rr = rfm[i][j];
-                const f32x2_t rf[2] = {{bf_lo(rr.x), bf_hi(rr.x)}, {bf_lo(rr.y), bf_hi(rr.y)}};
+                const f32x2_t rf[2] = {{rfm[i][j][0], rfm[i][j][1]}, {rfm[i][j][2], rfm[i][j][3]}};
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     f32x2_t m;
