@@ -229,6 +229,8 @@ class Engine:
             self.tmp_c = zeros(big, bf16)
             # bottleneck gradients of the layers whose slab data gradients are applied together
             self.dgrad_group = max(1, min(4, int(getattr(model, 'dgrad_group', 4))))
+            self.ident_one = torch.ones(4096, dtype=f32, device=dev)
+            self.ident_zero = zeros(4096)
             self.dy1_bufs = [self.tmp_c] + [zeros(max(self.M1, self.M2) * cmax_mid, bf16) for _ in range(self.dgrad_group - 1)]
             # Dense-layer weight gradients on the side stream: their gradient inputs must not be overwritten by the
             # next layers while they wait, so every dense layer gets private buffers for them (288 GB of HBM)
@@ -659,9 +661,13 @@ class Engine:
             else:
                 WG(n_img=B, H=H, W=W, cin=a.cin, cout=a.d0, taps=1, dil=1, x=_r(A.x, a.off_in), ldx=A.C, dz=_r(dy1),
                    lddz=a.d0, dw=self.PG(a.prefix + '.conv1.weight'))
+                # no BatchNorm in front of this block (its input is the ReLU output of norm5): the mask is that of the
+                # stored value itself, written as the identity scale/shift so that the launch has the form of the
+                # persistent slab data-gradient kernel
                 C(n_img=B, H=H, W=W, cin=a.d0, cout=a.cin, taps=1, dil=1, x=_r(dy1), ldx=a.d0,
                   w=self.WT16(a.prefix + '.conv1.weight'), epi_relu=1, ref=_r(A.x, a.off_in), ldref=A.C,
-                  g=_r(A.g, a.off_in), ldg=A.C, g_accumulate=1)
+                  e_scale=_r(self.ident_one), e_shift=_r(self.ident_zero), e_mean=_r(self.ident_zero),
+                  e_rstd=_r(self.ident_one), g=_r(A.g, a.off_in), ldg=A.C, g_accumulate=1)
 
         if self.mobilenet:
             self._build_backward_mobilenet(ops, C, WG, gradx, slab_extract, bn_bwd, bn_apply, zero)
