@@ -299,6 +299,20 @@ def test_rowwise(C):
     close(out['x'][0], out['x'][1], 1e-2, 'avgpool_bwd.x')
 
 
+@pytest.mark.parametrize('C,dr_f32', [(192, 0), (192, 1), (96, 0), (48, 0), (1104, 0), (8, 1)])
+def test_bn_bwd_apply_contiguous(C, dr_f32):
+    """dy = A*dr + B*y + C on unpadded tensors without column sums: the flat chunk-stream form (any channel count keeps
+    every lane busy; the grid stride is a multiple of the chunks per row)."""
+    gen = torch.Generator().manual_seed(500 + C + dr_f32)
+    M = 2 * 23 * 31 + 5
+    dr = torch.randn(M * C, generator=gen)
+    f = dict(M=M, C=C, dr=Ref(dr if dr_f32 else bf(dr)), lddr=C, dr_f32=dr_f32, y=Ref(bf(torch.randn(M * C, generator=gen))),
+             ldy=C, coefA=Ref(torch.randn(C, generator=gen)), coefB=Ref(torch.randn(C, generator=gen)),
+             coefC=Ref(torch.randn(C, generator=gen)), dy=Ref(torch.zeros(M * C, dtype=torch.bfloat16)), lddy=C, colsum=None)
+    out = run_both('bn_bwd_apply', f)
+    close(out['dy'][0], out['dy'][1], 1e-2, 'bn_bwd_apply(flat).dy')
+
+
 def test_stem_ops():
     gen = torch.Generator().manual_seed(11)
     n, H, W, C = 2, 24, 40, 96
