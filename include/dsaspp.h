@@ -400,6 +400,21 @@ typedef struct dsaspp_ce_desc {
 int dsaspp_upsample8_ce(const dsaspp_ce_desc* d, dsaspp_stream_t stream);
 int dsaspp_ce_finalize(const dsaspp_ce_desc* d, dsaspp_stream_t stream);
 
+/* The two calls above in one, without any device allocation by caller or library.  It has no counterpart
+ * in the reference; it is for callers that cannot allocate device memory around the loss: code under HIP
+ * graph capture, tight serving / evaluation loops, harnesses that forbid hipMalloc.  The fp32 gradient
+ * staging (`dlogits`) and the loss accumulators (`accum`) live in a built-in per-GPU array instead of
+ * caller buffers: d->dlogits and d->accum are ignored (may be NULL).  Inputs logits/labels and outputs
+ * loss (required), dlogits_bf16 and dbias (optional, dbias is added to) are the caller's, with the
+ * meaning they have in dsaspp_upsample8_ce + dsaspp_ce_finalize.
+ * Limit: n_img*h*w <= DSASPP_NOALLOC_MAX_PIXELS low-resolution pixels and ldl <= 32; larger calls fail
+ * with an error and touch nothing.  The built-in array (16 MiB) stays resident on every GPU the library
+ * runs on until the process ends.  All calls on one GPU share it: calls that overlap on one GPU (two
+ * streams, two threads) race; serialise them.  The first call on a GPU looks the array's device address
+ * up (hipGetSymbolAddress), so make that first call outside a graph capture. */
+#define DSASPP_NOALLOC_MAX_PIXELS 131072
+int dsaspp_upsample8_ce_loss_noalloc(const dsaspp_ce_desc* d, dsaspp_stream_t stream);
+
 /* Materialised x8 upsample for the plain forward() API: fp32 NHWC low-res -> fp32 NCHW
  * [N][n_class][8h][8w]; its adjoint; and the inference variant that writes only the arg-max
  * class per pixel (replaces Upsample + F.softmax + argmax, reference graph_seg_test.py:144-146,62). */

@@ -149,6 +149,8 @@ def load():
             fn = getattr(lib, entry)
             fn.argtypes = [ctypes.POINTER(struct), ctypes.c_void_p]
             fn.restype = ctypes.c_int
+    lib.dsaspp_upsample8_ce_loss_noalloc.argtypes = [ctypes.POINTER(ce_desc), ctypes.c_void_p]
+    lib.dsaspp_upsample8_ce_loss_noalloc.restype = ctypes.c_int
     lib.dsaspp_adam_step.argtypes = [ctypes.POINTER(adam_desc), ctypes.c_void_p]
     lib.dsaspp_cast_bf16.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
     lib.dsaspp_weight_transpose.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,

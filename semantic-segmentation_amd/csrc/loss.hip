@@ -8,6 +8,7 @@
 // low-resolution gradient, which leaves as contiguous fp32 atomics.  HBM traffic is the
 // low-resolution logits, the int64 labels and the low-resolution gradient.
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -318,6 +319,61 @@ extern "C" int dsaspp_ce_finalize(const dsaspp_ce_desc* d, dsaspp_stream_t strea
     hipLaunchKernelGGL(ce_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d);
     DS_LAUNCH_CHECK("ce_finalize");
     return 0;
+}
+
+// ---------------------------------------------------------------- allocation-free fused loss
+// Working memory of dsaspp_upsample8_ce_loss_noalloc: the two loss accumulators (first 64 floats) and the fp32
+// low-resolution gradient the cells add into.  One copy per GPU, resident from the moment the code object is loaded on
+// that GPU until the process ends; every call on a GPU uses that GPU's copy.
+#define NOALLOC_MAX_PIXELS DSASPP_NOALLOC_MAX_PIXELS   /* low-resolution pixels per call (four 1024x2048 images) */
+#define NOALLOC_LD 32                        /* floats per pixel row of the gradient staging */
+#define NOALLOC_HEAD 64                      /* floats in front of the gradient staging */
+static __device__ __align__(256) float scratch[NOALLOC_HEAD + (size_t)NOALLOC_MAX_PIXELS * NOALLOC_LD];
+
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static float* noalloc_ptr[NOALLOC_MAX_DEVICES];       // device address of `scratch` on each GPU, resolved once
+static std::mutex noalloc_mutex;
+
+// Device address of this GPU's copy of `scratch` (the array's name is only a host-side handle: kernels and
+// hipMemsetAsync must be given the address hipGetSymbolAddress returns, looked up with that GPU current).
+static int noalloc_scratch(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    DS_REQUIRE(e == hipSuccess, "upsample8_ce_loss_noalloc: hipGetDevice: %s", hipGetErrorString(e));
+    DS_REQUIRE(dev >= 0 && dev < NOALLOC_MAX_DEVICES, "upsample8_ce_loss_noalloc: device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(noalloc_mutex);
+    if (!noalloc_ptr[dev]) {
+        float* p = nullptr;
+        e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));
+        DS_REQUIRE(e == hipSuccess && p != nullptr, "upsample8_ce_loss_noalloc: hipGetSymbolAddress: %s", hipGetErrorString(e));
+        noalloc_ptr[dev] = p;
+    }
+    *out = noalloc_ptr[dev];
+    return 0;
+}
+
+extern "C" int dsaspp_upsample8_ce_loss_noalloc(const dsaspp_ce_desc* d, dsaspp_stream_t stream) {
+    DS_REQUIRE(d && d->n_img > 0 && d->h > 0 && d->w > 0, "upsample8_ce_loss_noalloc: bad geometry");
+    DS_REQUIRE(d->n_class > 0 && d->n_class <= NC_MAX && d->ldl >= d->n_class,
+               "upsample8_ce_loss_noalloc: n_class must be in [1,32] and ldl >= n_class");
+    DS_REQUIRE(d->logits && d->labels && d->loss, "upsample8_ce_loss_noalloc: null tensor");
+    DS_REQUIRE(d->ldl <= NOALLOC_LD && (!d->dlogits_bf16 || d->lddb <= 32), "upsample8_ce_loss_noalloc: ldl/lddb must be <= 32");
+    const int64_t M = (int64_t)d->n_img * d->h * d->w;
+    DS_REQUIRE(M <= NOALLOC_MAX_PIXELS,
+               "upsample8_ce_loss_noalloc: %lld low-resolution pixels exceed the built-in working memory (%d); "
+               "use dsaspp_upsample8_ce + dsaspp_ce_finalize with caller-provided buffers",
+               (long long)M, NOALLOC_MAX_PIXELS);
+    float* ws = nullptr;
+    if (int rc = noalloc_scratch(&ws)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    // the array keeps the previous call's sums: clear exactly what this call adds into
+    hipError_t e = hipMemsetAsync(ws, 0, (NOALLOC_HEAD + (size_t)M * d->ldl) * sizeof(float), s);
+    DS_REQUIRE(e == hipSuccess, "upsample8_ce_loss_noalloc: hipMemsetAsync: %s", hipGetErrorString(e));
+    dsaspp_ce_desc c = *d;
+    c.accum = ws;
+    c.dlogits = ws + NOALLOC_HEAD;
+    if (int rc = dsaspp_upsample8_ce(&c, stream)) return rc;
+    return dsaspp_ce_finalize(&c, stream);
 }
 
 static int up_common(const dsaspp_up_desc* d, const char* who) {
