@@ -87,12 +87,15 @@ class _LogitsFn(torch.autograd.Function):
             raise RuntimeError('DenseASPP: backward needs the forward pass to run in train() mode')
         prog = eng.prog_up_bwd()
         eng.grad_full.view(grad.shape).copy_(grad)
-        saved = model._gflat
-        # gradients of this pass only: autograd does the accumulation into .grad
+        # The backward program writes into the flat gradient arena, which the .grad views of a previous train_step
+        # (or bind_grads) alias: keep its contents, compute this pass's gradients alone, hand them to autograd as a
+        # private copy (autograd does the accumulation into .grad) and put the arena back as it was.
+        held = model._gflat.clone()
         model._gflat_zero()
         prog.run()
         eng._bwd.run()
-        g = saved.clone()
+        g = model._gflat.clone()
+        model._gflat.copy_(held)
         grads = [model.arena.view(g, n) for n in model._param_names]
         return (None, None) + tuple(grads)
 
@@ -170,6 +173,7 @@ class DenseASPP(nn.Module):
         # dense-layer weight gradients on a second HIP stream (per-layer gradient buffers, ~20 GB at batch 16):
         # +1.9 % step throughput measured, but overlapped kernels time longer individually, so it is off by default
         self.side_wgrad = False
+        self.max_engines = 4                     # (batch, height, width, mode) configurations kept with their buffers
         self._flat = None
         self._gflat = None
         self._w16 = None
@@ -207,7 +211,9 @@ class DenseASPP(nn.Module):
             nk = k
             if prefix == '' and nk.startswith('module.'):
                 nk = nk[len('module.'):]
-            if '.conv.' not in nk or 'denselayer' in nk or nk.startswith('ASPP_'):
+            # the key as this module names it: under an nn.DataParallel wrapper the hook runs with prefix 'module.'
+            rel = nk[len(prefix):] if prefix and nk.startswith(prefix) else nk
+            if '.conv.' not in rel or 'denselayer' in rel or rel.startswith('ASPP_'):
                 # legacy dotted child names of dense layers / ASPP blocks ("norm.1" -> "norm1"); the MobileNet
                 # trunk's "features.features.<i>.conv.<j>" names are Sequential indices and stay as they are
                 nk = _LEGACY.sub(lambda m: '.%s%s.' % (m.group(1), m.group(2)), nk)
@@ -259,10 +265,63 @@ class DenseASPP(nn.Module):
                 or self.classification[1].bias.data_ptr() != self._flat.data_ptr() + 4 * self.arena.by_name['classification.1.bias'].off):
             self._flatten()
 
+    # ------------------------------------------------------------------ nn.DataParallel over several devices
+    # nn.DataParallel(model) without device_ids (graph_seg_main.py:173) replicates the module on every visible GPU each
+    # forward: torch broadcasts parameters and buffers and builds shallow module copies whose attributes are those
+    # broadcast tensors.  The kernels need a flat arena, engines and activation buffers per device, so every device
+    # other than the master's gets one persistent worker model (built on first use); a replica's forward copies the
+    # broadcast values into its worker and runs the worker's programs, with the broadcast copies as the autograd inputs
+    # so that torch's own reduce-add brings the replica gradients back to the master parameters.  BatchNorm running
+    # statistics of the other devices are dropped, as with plain nn.BatchNorm2d under nn.DataParallel.  One process
+    # per GPU (semantic_segmentation_amd.distributed) remains the fast path: this one re-broadcasts 4 bytes per
+    # parameter per device and step.
     def _replicate_for_data_parallel(self):
-        raise RuntimeError('DenseASPP (MI355X) runs one process per GPU: wrap it as nn.DataParallel(model, device_ids=[gpu]) '
-                           'or launch one rank per device and use semantic_segmentation_amd.distributed; '
-                           'multi-device nn.DataParallel replication is not supported')
+        replica = super()._replicate_for_data_parallel()
+        replica.__dict__['_dp_master'] = self.__dict__.get('_dp_master', self)
+        return replica
+
+    def _dp_worker(self, device):
+        """The model that runs a replica's work on `device`: the master itself on its own device."""
+        self._check_arena()
+        if device == self._flat.device and not getattr(self, '_dp_force_worker', False):
+            return self
+        workers = self.__dict__.setdefault('_dp_workers', {})
+        w = workers.get(device)
+        if w is None:
+            if not getattr(self, '_dp_warned', False):
+                import warnings
+                warnings.warn('DenseASPP under multi-device nn.DataParallel: every extra device keeps a full worker copy and '
+                              'parameters are re-broadcast each step; one process per GPU with '
+                              'semantic_segmentation_amd.distributed.GradReducer is the fast path', stacklevel=3)
+                self._dp_warned = True
+            w = DenseASPP(self.spec.cfg, n_class=self.spec.n_class, output_stride=self.spec.output_stride).to(device)
+            for k in ('compute_dtype', 'grad_slab_dtype', 'bn_grad_dtype', 'dgrad_group'):
+                setattr(w, k, getattr(self, k))
+            if self._backend is not None and not hasattr(self._backend, 'lib'):
+                w.set_backend(type(self._backend)())        # test backends (CPU kernel model) follow the master
+            workers[device] = w
+        return w
+
+    def _replica_forward(self, x):
+        master = self._dp_master
+        worker = master._dp_worker(x.device)
+        copies = []
+        for name in master._param_names:
+            obj = self
+            for part in name.split('.'):
+                obj = getattr(obj, part)
+            copies.append(obj)
+        worker.train(self.training)
+        if worker is not master:
+            with torch.no_grad():
+                for name, c in zip(master._param_names, copies):
+                    worker.arena.view(worker._flat, name).copy_(c)
+                mine = dict(self.named_buffers())
+                for name, b in worker.named_buffers():
+                    b.copy_(mine[name])
+        if torch.is_grad_enabled() and self.training:
+            return _LogitsFn.apply(worker, x, *copies)
+        return worker.forward(x)
 
     def bind_grads(self):
         """Point every Parameter's .grad at its slice of the flat gradient arena."""
@@ -272,6 +331,20 @@ class DenseASPP(nn.Module):
 
     def _gflat_zero(self):
         self._gflat.zero_()
+
+    def sync_grads_to_arena(self):
+        """Make the flat gradient arena hold what the Parameters' .grad hold.  After train_step the .grad tensors ARE
+        views of the arena; after loss.backward() through model(x) autograd may have installed tensors of its own
+        (first backward) -- those are copied in and the views re-bound, parameters without a gradient count as zero."""
+        named = dict(self.named_parameters())
+        for name in self._param_names:
+            p = named[name]
+            view = self.arena.view(self._gflat, name)
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+            p.grad = view
 
     # ------------------------------------------------------------------ backend / engines
     def _get_backend(self):
@@ -308,7 +381,13 @@ class DenseASPP(nn.Module):
             self._check_arena()
             eng = Engine(self, batch, height, width, bool(training), self._get_backend(), self._flat.device)
             eng.programs()
+            # every engine owns a full activation set: keep the most recently used few (a short last batch, a
+            # validation size), drop the oldest beyond that
+            while len(self._engines) >= self.max_engines:
+                self._engines.pop(next(iter(self._engines)))
             self._engines[key] = eng
+        else:
+            self._engines[key] = self._engines.pop(key)       # most recently used last
         return eng
 
     def refresh_weights(self):
@@ -337,6 +416,8 @@ class DenseASPP(nn.Module):
 
     def forward(self, x):
         """Full-resolution logits N x n_class x H x W (fp32), differentiable w.r.t. the parameters."""
+        if self.__dict__.get('_dp_master') is not None:
+            return self._replica_forward(x)
         if torch.is_grad_enabled() and self.training:
             params = [p for _, p in self.named_parameters()]
             return _LogitsFn.apply(self, x, *params)

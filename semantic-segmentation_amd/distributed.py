@@ -13,11 +13,33 @@ import torch
 import torch.distributed as dist
 
 
+def broadcast_model(model, src=0, group=None):
+    """Make every rank start from rank `src`'s replica: the flat fp32 parameter arena and every buffer (BatchNorm
+    running statistics and batch counters) are broadcast, as DistributedDataParallel does when it wraps a module."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    model._check_arena()
+    dist.broadcast(model._flat, src=src, group=group)
+    for _, b in model.named_buffers():
+        dist.broadcast(b, src=src, group=group)
+
+
+def all_reduce_mean(t, group=None):
+    """Mean of a small tensor over the ranks (the loss value, for logging only)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t /= dist.get_world_size(group)
+    return t
+
+
 class GradReducer:
-    def __init__(self, model, engine, bucket_mb=25.0, group=None, always=False):
+    def __init__(self, model, engine, bucket_mb=25.0, group=None, always=False, broadcast=True):
         self.model, self.engine, self.group = model, engine, group
         self.always = always             # issue the collectives even in a one-rank group (rehearsal of the N > 1 path)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if broadcast:
+            broadcast_model(model, 0, group)
         gflat = model._gflat
         n = gflat.numel()
         ops = engine._bwd.keepalive if hasattr(engine._bwd, 'keepalive') else engine._bwd.ops
@@ -72,4 +94,13 @@ class GradReducer:
             eng._bwd.run(first=pos, last=self.n_ops)
         for h in handles:
             h.wait()
-        return 1.0 / self.world          # scale to apply to the summed gradients (FusedAdam grad_scale)
+        # the collectives summed: the optimizer divides (FusedAdam.step reads this when no grad_scale is passed;
+        # with another optimizer call average_grads() first)
+        self.model._grad_scale = 1.0 / self.world
+        return self.model._grad_scale
+
+    def average_grads(self):
+        """Divide the summed gradients in place, for optimizers that do not take a gradient scale (torch.optim.Adam)."""
+        if self.world > 1:
+            self.model._gflat.mul_(1.0 / self.world)
+        self.model._grad_scale = 1.0

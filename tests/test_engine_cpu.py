@@ -157,3 +157,119 @@ def test_output_stride_16_fp32(fp32_model):
         assert float((br[n].float() - b.float()).abs().max()) < 1e-4, n
     with pytest.raises(ValueError):
         mod.eval()(torch.zeros(1, 3, 72, 96))          # 72 is a multiple of 8 but not of 16
+
+
+def test_legacy_keys_through_dataparallel_wrapper():
+    """Upstream checkpoints name the children 'norm.1' / 'conv.2' and are loaded INTO the nn.DataParallel wrapper
+    (graph_seg_test.py:131-135): the key hook then runs with prefix 'module.' and must still rewrite ASPP keys."""
+    import denseASPP
+    ref, mod = make_pair(TINY_CFG)
+    sd = ref.state_dict()
+    legacy = {}
+    for k, v in sd.items():
+        k2 = k
+        for a, b in (('.norm1.', '.norm.1.'), ('.norm2.', '.norm.2.'), ('.conv1.', '.conv.1.'), ('.conv2.', '.conv.2.')):
+            k2 = k2.replace(a, b)
+        legacy['module.' + k2] = v
+    assert any(k.startswith('module.ASPP_6.conv.1.') for k in legacy)
+    wrapped = torch.nn.DataParallel(denseASPP.DenseASPP(TINY_CFG))
+    wrapped.load_state_dict(legacy)                  # strict
+    for k, v in wrapped.module.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+
+
+def _fake_replicate(network, n):
+    """What torch.nn.parallel.replicate does, with autograd-connected CPU copies instead of a CUDA broadcast."""
+    params = list(network.parameters())
+    pidx = {p: i for i, p in enumerate(params)}
+    pcopies = [[p * 1.0 for p in params] for _ in range(n)]
+    bufs = list(network.buffers())
+    bidx = {b: i for i, b in enumerate(bufs)}
+    bcopies = [[b.clone() for b in bufs] for _ in range(n)]
+    modules = list(network.modules())
+    midx = {m: i for i, m in enumerate(modules)}
+    copies = [[m._replicate_for_data_parallel() for m in modules] for _ in range(n)]
+    for i, m in enumerate(modules):
+        for key, child in m._modules.items():
+            for j in range(n):
+                setattr(copies[j][i], key, copies[j][midx[child]])
+        for key, p in m._parameters.items():
+            for j in range(n):
+                if p is None:
+                    copies[j][i]._parameters[key] = None
+                else:
+                    setattr(copies[j][i], key, pcopies[j][pidx[p]])
+        for key, b in m._buffers.items():
+            for j in range(n):
+                if b is None:
+                    copies[j][i]._buffers[key] = None
+                else:
+                    setattr(copies[j][i], key, bcopies[j][bidx[b]])
+    return [copies[j][0] for j in range(n)]
+
+
+def test_dataparallel_replicas(fp32_model):
+    """nn.DataParallel(model) without device_ids (graph_seg_main.py:173) replicates the module per device and step.
+    The replica mechanics are exercised here on the CPU: two replicas made the way torch's replicate() makes them,
+    one served by the master model and one by a separate worker copy, each on its half of the batch; the gradients
+    that flow back to the master parameters must equal those of the two halves run one after the other."""
+    ref, mod = make_pair(TINY_CFG)
+    mod.set_backend(kernel_model.ModelBackend())
+    mod.train()
+    x, labels = make_batch(2, 64, 96)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+    want = None
+    for i in range(2):
+        for p in mod.parameters():
+            p.grad = None
+        torch.manual_seed(3 + i)                     # the Dropout2d masks are drawn inside the forward call
+        crit(mod(x[i:i + 1]), labels[i:i + 1]).backward()
+        g = torch.cat([p.grad.reshape(-1) for p in mod.parameters()])
+        want = g if want is None else want + g
+    for p in mod.parameters():
+        p.grad = None
+    reps = _fake_replicate(mod, 2)
+    assert all(r._dp_master is mod for r in reps)
+    mod._dp_force_worker = True                      # the second replica runs on a worker copy, as on another device
+    with pytest.warns(UserWarning):
+        mod._dp_worker(torch.device('cpu'))          # built here: its random initialisation would shift the mask draws
+    mod._dp_force_worker = False
+    torch.manual_seed(3)
+    out0 = reps[0](x[0:1])
+    mod._dp_force_worker = True
+    torch.manual_seed(4)
+    out1 = reps[1](x[1:2])
+    assert len(mod._dp_workers) == 1
+    (crit(out0, labels[0:1]) + crit(out1, labels[1:2])).backward()
+    got = torch.cat([p.grad.reshape(-1) for p in mod.parameters()])
+    assert float((got - want).norm() / want.norm()) < 1e-5
+    # eval-mode replicas give the master's logits
+    mod.eval()
+    reps = _fake_replicate(mod, 2)
+    with torch.no_grad():
+        ya, yb, ym = reps[0](x), reps[1](x), mod(x)
+    assert torch.allclose(ya, ym, atol=1e-6) and torch.allclose(yb, ym, atol=1e-5)
+
+
+def test_autograd_backward_keeps_arena_gradients(fp32_model):
+    """loss.backward() through model(x) after a train_step must accumulate onto, not wipe, the gradients that the
+    Parameters' .grad (views of the flat gradient arena) already hold."""
+    ref, mod = make_pair(TINY_CFG)
+    mod.set_backend(kernel_model.ModelBackend())
+    mod.train()
+    x, labels = make_batch(1, 64, 64)
+    masks = make_dropout_masks(ref, 1, torch.Generator().manual_seed(5))
+    mod.train_step(x, labels, dropout_masks=masks)
+    g1 = mod._gflat.clone()
+    assert float(g1.abs().max()) > 0
+    p0 = next(mod.parameters())
+    assert p0.grad.data_ptr() == mod._gflat.data_ptr() + 4 * mod.arena.by_name[mod._param_names[0]].off
+    mod.spec.dropout0 = mod.spec.dropout1 = 0.0      # the autograd path draws its own masks
+    eng = mod.engine(1, 64, 64, True)
+    eng.dropmask.fill_(1.0)
+    torch.nn.functional.cross_entropy(mod(x), labels, ignore_index=255).backward()
+    g_sum = mod._gflat.clone()
+    mod._gflat_zero()
+    torch.nn.functional.cross_entropy(mod(x), labels, ignore_index=255).backward()
+    g2 = mod._gflat.clone()
+    assert float((g_sum - (g1 + g2)).abs().max()) <= 1e-5 * float(g_sum.abs().max())

@@ -170,3 +170,75 @@ def test_fused_adam_matches_torch():
     torch.cuda.synchronize()
     for (n, p), (_, q) in zip(mod.named_parameters(), twin.named_parameters()):
         assert torch.allclose(p, q, atol=2e-6, rtol=1e-4), n
+
+
+def test_fused_adam_state_dict_round_trip():
+    """'optimizer': optimizer.state_dict() / optimizer.load_state_dict(...) of the reference's checkpoints
+    (graph_seg_main.py:199,280): FusedAdam writes and reads torch.optim.Adam's format.  Two steps with each
+    optimizer, states compared entry by entry, then each one's state is loaded into a fresh optimizer of the OTHER
+    kind and a third step must keep the two parameter sets together."""
+    from semantic_segmentation_amd.optim import FusedAdam
+    ref, mod = make_pair(TINY_CFG)
+    mod = mod.cuda().train()
+    x, labels = make_batch(2, 64, 64)
+    twin = copy.deepcopy(mod)
+    opt_t = torch.optim.Adam(twin.parameters(), lr=3e-4, weight_decay=1e-4)
+    opt_f = FusedAdam(mod, lr=3e-4, weight_decay=1e-4)
+    g = torch.Generator(device='cuda')
+
+    def both_step(of, ot, seed):
+        g.manual_seed(seed)
+        mod.train_step(x.cuda(), labels.cuda(), generator=g)
+        for (n, p), (_, q) in zip(mod.named_parameters(), twin.named_parameters()):
+            q.grad = p.grad.detach().clone()
+        of.step()
+        ot.step()
+
+    for step in range(2):
+        both_step(opt_f, opt_t, step)
+    sd_f, sd_t = opt_f.state_dict(), opt_t.state_dict()
+    assert opt_f.global_step == 2
+    assert sorted(sd_f['state'].keys()) == sorted(sd_t['state'].keys())
+    assert sd_f['param_groups'][0]['params'] == sd_t['param_groups'][0]['params']
+    for k in ('lr', 'betas', 'eps', 'weight_decay', 'amsgrad'):
+        assert sd_f['param_groups'][0][k] == sd_t['param_groups'][0][k], k
+    for i, st in sd_t['state'].items():
+        assert float(sd_f['state'][i]['step']) == float(st['step'])
+        for k in ('exp_avg', 'exp_avg_sq'):
+            a, b = sd_f['state'][i][k], st[k]
+            assert a.shape == b.shape, (i, k)
+            assert torch.allclose(a, b, atol=1e-7, rtol=1e-4), (i, k)
+    # cross-load: torch's state into a fresh FusedAdam, FusedAdam's into a fresh torch Adam
+    opt_f2 = FusedAdam(mod, lr=1.0)
+    opt_f2.load_state_dict(sd_t)
+    opt_t2 = torch.optim.Adam(twin.parameters(), lr=1.0)
+    opt_t2.load_state_dict(sd_f)
+    assert opt_f2.global_step == 2 and opt_f2.param_groups[0]['lr'] == 3e-4
+    both_step(opt_f2, opt_t2, 7)
+    torch.cuda.synchronize()
+    for (n, p), (_, q) in zip(mod.named_parameters(), twin.named_parameters()):
+        assert torch.allclose(p, q, atol=2e-6, rtol=1e-4), n
+    torch.save({'global_step': opt_f2.global_step, 'optimizer': opt_f2.state_dict()}, '/tmp/dsaspp_opt_ckpt.pth')
+    back = torch.load('/tmp/dsaspp_opt_ckpt.pth', weights_only=True)
+    assert back['global_step'] == 3 and len(back['optimizer']['state']) == len(sd_t['state'])
+
+
+def test_fused_adam_after_autograd_backward():
+    """FusedAdam.step after loss.backward() through model(x): the gradients autograd installed are brought into the
+    flat arena first (they are not views of it on the first backward)."""
+    from semantic_segmentation_amd.optim import FusedAdam
+    ref, mod = make_pair(TINY_CFG)
+    mod = mod.cuda().train()
+    mod.spec.dropout0 = mod.spec.dropout1 = 0.0
+    x, labels = make_batch(1, 64, 64)
+    twin = copy.deepcopy(mod)
+    opt_t = torch.optim.Adam(twin.parameters(), lr=3e-4)
+    opt_f = FusedAdam(mod, lr=3e-4)
+    torch.nn.functional.cross_entropy(mod(x.cuda()), labels.cuda(), ignore_index=255).backward()
+    for (n, p), (_, q) in zip(mod.named_parameters(), twin.named_parameters()):
+        q.grad = p.grad.detach().clone()
+    opt_f.step()
+    opt_t.step()
+    torch.cuda.synchronize()
+    for (n, p), (_, q) in zip(mod.named_parameters(), twin.named_parameters()):
+        assert torch.allclose(p, q, atol=2e-6, rtol=1e-4), n
