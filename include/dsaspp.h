@@ -123,6 +123,16 @@ typedef struct dsaspp_wgrad_desc {
     int32_t lddz;
     float* dw;                /* fp32 [cout][taps*cin] */
     int32_t ksplit;           /* pixel-range splits (<=0: library picks) */
+    /* Extra sources (taps == 1, in_mask == NULL, cout <= 192): n_src in 2..4 computes the weight gradients of
+     * several 1x1 layers that read the SAME input tensor x (the dense layers of one block: each normalises the
+     * shared slab prefix with its own BatchNorm) in one pass, so that x is fetched once per group instead of once
+     * per layer:   dw_s[q][c] += sum_m dz_s[m][q] * relu(x[m][c] * sc_s[c] + sh_s[c])   for c < cin_s.
+     * Source 0 is (dz, dw, in_scale, in_shift, cin); sources 1..3 follow.  All sources share x, ldx, cout, lddz and
+     * in_relu; every source needs its scale/shift tables. */
+    int32_t n_src;
+    const void* dz1; float* dw1; const float* sc1; const float* sh1; int32_t cin1;
+    const void* dz2; float* dw2; const float* sc2; const float* sh2; int32_t cin2;
+    const void* dz3; float* dw3; const float* sc3; const float* sh3; int32_t cin3;
 } dsaspp_wgrad_desc;
 
 int dsaspp_conv_wgrad(const dsaspp_wgrad_desc* d, dsaspp_stream_t stream);

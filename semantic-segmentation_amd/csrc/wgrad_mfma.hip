@@ -343,6 +343,7 @@ extern "C" int dsaspp_conv_wgrad(const dsaspp_wgrad_desc* dp, dsaspp_stream_t st
     DS_REQUIRE(((uintptr_t)d.x & 15) == 0 && ((uintptr_t)d.dz & 15) == 0, "conv_wgrad: operands must be 16-byte aligned");
     DS_REQUIRE((d.in_scale == nullptr) == (d.in_shift == nullptr), "conv_wgrad: in_scale/in_shift must come together");
     if (d.in_mask) DS_REQUIRE(d.in_mask_ld % 4 == 0, "conv_wgrad: in_mask_ld must be a multiple of 4");
+    if (d.n_src >= 2) return dsaspp_wgrad_group_launch(d, s);
     const int co = d.cout;
     if (co <= 32) return launch<32, 192, 1, 4>(d, s);
     if (co <= 48) return launch<48, 192, 1, 4>(d, s);

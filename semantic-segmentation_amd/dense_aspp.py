@@ -170,6 +170,7 @@ class DenseASPP(nn.Module):
         self.grad_slab_dtype = torch.bfloat16    # dtype of the feature-slab gradient (torch.float32: exact accumulation, 2x traffic)
         self.bn_grad_dtype = torch.bfloat16      # dtype of the BatchNorm-backward inputs (torch.float32: unrounded)
         self.dgrad_group = 4                     # dense layers whose slab data gradients share one pass (1..4)
+        self.wgrad_group = True                  # ... and whose bottleneck weight gradients share one pass over the slab
         # dense-layer weight gradients on a second HIP stream (per-layer gradient buffers, ~20 GB at batch 16):
         # +1.9 % step throughput measured, but overlapped kernels time longer individually, so it is off by default
         self.side_wgrad = False
@@ -295,7 +296,7 @@ class DenseASPP(nn.Module):
                               'semantic_segmentation_amd.distributed.GradReducer is the fast path', stacklevel=3)
                 self._dp_warned = True
             w = DenseASPP(self.spec.cfg, n_class=self.spec.n_class, output_stride=self.spec.output_stride).to(device)
-            for k in ('compute_dtype', 'grad_slab_dtype', 'bn_grad_dtype', 'dgrad_group'):
+            for k in ('compute_dtype', 'grad_slab_dtype', 'bn_grad_dtype', 'dgrad_group', 'wgrad_group'):
                 setattr(w, k, getattr(self, k))
             if self._backend is not None and not hasattr(self._backend, 'lib'):
                 w.set_backend(type(self._backend)())        # test backends (CPU kernel model) follow the master

@@ -229,6 +229,7 @@ class Engine:
             self.tmp_c = zeros(big, bf16)
             # bottleneck gradients of the layers whose slab data gradients are applied together
             self.dgrad_group = max(1, min(4, int(getattr(model, 'dgrad_group', 4))))
+            self.wgrad_group = bool(getattr(model, 'wgrad_group', True))
             self.ident_one = torch.ones(4096, dtype=f32, device=dev)
             self.ident_zero = zeros(4096)
             self.dy1_bufs = [self.tmp_c] + [zeros(max(self.M1, self.M2) * cmax_mid, bf16) for _ in range(self.dgrad_group - 1)]
@@ -729,6 +730,9 @@ class Engine:
                 gi += len(grp)
                 c_lo = grp[-1].cin
                 grp_dy1 = []
+                # the group's bottleneck weight gradients in one launch (the slab prefix is streamed once for all of
+                # them): needs the group's bottleneck gradients side by side, which the grouped data gradient needs too
+                group_wgrad = self.wgrad_group and len(grp) > 1 and not self.side_wgrad and grp[0].mid <= 192
                 for k, l in enumerate(grp):
                     n1, n2 = l.prefix + '.norm1', l.prefix + '.norm2'
                     y1 = self.y1[l.prefix]
@@ -749,11 +753,12 @@ class Engine:
                       s_acc=_r(self.acc[l.prefix + '.s2']))
                     bn_bwd(n2, l.mid, l.prefix + '.s2', M, 0)
                     bn_apply(l.mid, M, dr, y1, dy1k)
-                    WG(n_img=B, H=H, W=W, cin=l.cin, cout=l.mid, taps=1, dil=1, x=_r(slab.x), ldx=slab.C,
-                       in_scale=self.bnt(n1, 'scale', l.cin), in_shift=self.bnt(n1, 'shift', l.cin), in_relu=1, dz=_r(dy1k),
-                       lddz=l.mid, dw=self.PG(l.prefix + '.conv1.weight'))
-                    if side:
-                        ops.mark_side()
+                    if not group_wgrad:
+                        WG(n_img=B, H=H, W=W, cin=l.cin, cout=l.mid, taps=1, dil=1, x=_r(slab.x), ldx=slab.C,
+                           in_scale=self.bnt(n1, 'scale', l.cin), in_shift=self.bnt(n1, 'shift', l.cin), in_relu=1, dz=_r(dy1k),
+                           lddz=l.mid, dw=self.PG(l.prefix + '.conv1.weight'))
+                        if side:
+                            ops.mark_side()
                     cn = l.cin - c_lo
                     if cn > 0:     # channels produced by the later-processed layers of this group
                         C(n_img=B, H=H, W=W, cin=l.mid, cout=cn, taps=1, dil=1, x=_r(dy1k), ldx=l.mid,
@@ -762,6 +767,17 @@ class Engine:
                           e_mean=_r(slab.mean, c_lo), e_rstd=_r(slab.rstd, c_lo), s_acc=_r(self.acc[l.prefix + '.s1'], c_lo),
                           s_ld=l.cin, g=_r(slab.g, c_lo), ldg=slab.C, g_accumulate=1)
                         bn_bwd_slice(n1, l.cin, l.prefix + '.s1', M, slab, c_lo, cn)
+                if group_wgrad:
+                    wg = dict(n_src=len(grp))
+                    for k, l in enumerate(grp):
+                        n1 = l.prefix + '.norm1'
+                        src = (_r(grp_dy1[k]), self.PG(l.prefix + '.conv1.weight'), self.bnt(n1, 'scale', l.cin),
+                               self.bnt(n1, 'shift', l.cin), l.cin)
+                        names = ('dz', 'dw', 'in_scale', 'in_shift', 'cin') if k == 0 else \
+                            tuple(n + str(k) for n in ('dz', 'dw', 'sc', 'sh', 'cin'))
+                        wg.update(zip(names, src))
+                    WG(n_img=B, H=H, W=W, cout=grp[0].mid, taps=1, dil=1, x=_r(slab.x), ldx=slab.C, in_relu=1,
+                       lddz=grp[0].mid, **wg)
                 multi = dict(n_src=len(grp))
                 for k, l in enumerate(grp):
                     n1 = l.prefix + '.norm1'

@@ -13,7 +13,7 @@ CLASSES = ['untimed',
            'conv_kernel<128,64,2,2>', 'conv_kernel<128,32,4,1>',
            'wgrad_kernel<64,192,1,4>', 'wgrad_kernel<192,128,4,2>', 'wgrad_kernel<128,128,2,4>',
            'upce_kernel<19>', 'wgrad_kernel<48,192,1,4>', 'wgrad_kernel<32,192,1,4>', 'dgrad_group_kernel', 'conv3x3_halo_kernel',
-           'conv1x1_stream_kernel<192>', 'conv1x1_stream_kernel<128>']
+           'conv1x1_stream_kernel<192>', 'conv1x1_stream_kernel<128>', 'wgrad_group_kernel']
 
 
 def kernel_class(kind, f):
@@ -44,6 +44,8 @@ def kernel_class(kind, f):
         return 1 if pad192 <= pad128 else 2
     if kind == 'wgrad':
         co = f['cout']
+        if (f.get('n_src') or 0) > 1:
+            return 16
         if co <= 32:
             return 11
         if co <= 48:
@@ -60,6 +62,10 @@ def kernel_class(kind, f):
 
 def work(kind, f):
     """(flops, bytes) of one launch: algorithmic, i.e. what the operation needs, not what a kernel moves."""
+    if kind == 'wgrad' and (f.get('n_src') or 0) > 1:
+        M = f['n_img'] * f['H'] * f['W']
+        k = f['cin'] + sum(f['cin%d' % i] for i in range(1, f['n_src']))
+        return 2.0 * M * f['cout'] * k, 0.0
     if kind in ('conv', 'wgrad'):
         M = f['n_img'] * f['H'] * f['W']
         return 2.0 * M * f['cout'] * f['taps'] * f['cin'] * max(1, f.get('n_src') or 0), 0.0
@@ -79,6 +85,8 @@ def role(kind, f):
             return 'dgrad3x3' if f['taps'] == 9 else 'dgrad1x1'
         return 'fwd3x3' if f['taps'] == 9 else 'fwd1x1'
     if kind == 'wgrad':
+        if (f.get('n_src') or 0) > 1:
+            return 'wgrad1x1 x%d' % f['n_src']
         return 'wgrad3x3' if f['taps'] == 9 else 'wgrad1x1'
     return kind
 

@@ -120,6 +120,16 @@ def op_conv(f):
 def op_wgrad(f):
     n, H, W, cin, cout, taps, dil = f['n_img'], f['H'], f['W'], f['cin'], f['cout'], f['taps'], f['dil']
     M, hw = n * H * W, H * W
+    if f.get('n_src', 0) >= 2:
+        # several 1x1 layers reading the same input through their own scale/shift tables: one source at a time
+        assert taps == 1 and f['in_mask'] is None
+        srcs = [(f['dz'], f['dw'], f['in_scale'], f['in_shift'], cin)]
+        for k in range(1, f['n_src']):
+            srcs.append(tuple(f['%s%d' % (nm, k)] for nm in ('dz', 'dw', 'sc', 'sh', 'cin')))
+        for dz_r, dw_r, sc_r, sh_r, ci in srcs:
+            g = dict(f, n_src=0, dz=dz_r, dw=dw_r, in_scale=sc_r, in_shift=sh_r, cin=ci)
+            op_wgrad(g)
+        return
     x = _view(f['x'], M, cin, f['ldx']).to(torch.float32)
     a = _prologue(x, f, n, hw, cin)
     dz = _view(f['dz'], M, cout, f['lddz']).to(torch.float32)

@@ -201,6 +201,44 @@ WGRAD_CASES = [
 ]
 
 
+def wgrad_group_fields(n, H, W, cins, cout, ldx, relu=True, seed=0, ksplit=0):
+    """n_src = len(cins) 1x1 layers reading the same slab through their own scale/shift tables."""
+    gen = torch.Generator().manual_seed(300 + seed)
+    M = n * H * W
+    f = dict(n_img=n, H=H, W=W, cin=cins[0], cout=cout, taps=1, dil=1, x=Ref(bf(torch.randn(M * ldx, generator=gen))), ldx=ldx,
+             in_relu=int(relu), in_mask=None, in_mask_ld=0, lddz=cout, ksplit=ksplit, n_src=len(cins))
+    for k, ci in enumerate(cins):
+        dz = Ref(bf(torch.randn(M * cout, generator=gen)))
+        dw = Ref(torch.zeros(cout * ci))
+        sc = Ref(torch.rand(ci, generator=gen) + 0.5)
+        sh = Ref(torch.randn(ci, generator=gen) * 0.3)
+        if k == 0:
+            f.update(dz=dz, dw=dw, in_scale=sc, in_shift=sh)
+        else:
+            f.update({'dz%d' % k: dz, 'dw%d' % k: dw, 'sc%d' % k: sc, 'sh%d' % k: sh, 'cin%d' % k: ci})
+    return f
+
+
+WGRAD_GROUP_CASES = [
+    # (slab prefix widths of the grouped layers, bottleneck width): column tails, pixel tails, partly active top tiles
+    dict(n=2, H=9, W=13, cins=(336, 288, 240, 192), cout=192, ldx=384),
+    dict(n=1, H=16, W=24, cins=(144, 96), cout=192, ldx=160),
+    dict(n=2, H=10, W=10, cins=(264, 232, 200), cout=128, ldx=272, ksplit=3),
+    dict(n=3, H=8, W=8, cins=(96, 128, 160, 64), cout=128, ldx=160, relu=False),      # unsorted widths
+    dict(n=1, H=7, W=9, cins=(520, 472, 424, 376), cout=176, ldx=528, ksplit=1),
+]
+
+
+@pytest.mark.parametrize('case', range(len(WGRAD_GROUP_CASES)))
+def test_wgrad_group(case):
+    f = wgrad_group_fields(seed=case, **WGRAD_GROUP_CASES[case])
+    out = run_both('wgrad', f)
+    for k in range(f['n_src']):
+        name = 'dw' if k == 0 else 'dw%d' % k
+        assert float(out[name][0].abs().max()) > 0
+        close(out[name][0], out[name][1], 5e-3, 'wgrad_group.' + name)
+
+
 @pytest.mark.parametrize('case', range(len(WGRAD_CASES)))
 def test_wgrad(case):
     f = wgrad_fields(seed=case, **WGRAD_CASES[case])

@@ -58,6 +58,15 @@ cases = {
  'wgrad1x1': ('wgrad', dict(n_img=n, H=H, W=W, cin=CIN, cout=192, taps=1, dil=1, x=Ref(slab), ldx=LD, in_scale=Ref(sc1), in_shift=Ref(sh1), in_relu=1, in_mask=None, in_mask_ld=0, dz=Ref(y1), lddz=192, dw=Ref(dw1), ksplit=0)),
  'wgrad3x3': ('wgrad', dict(n_img=n, H=H, W=W, cin=192, cout=48, taps=9, dil=2, x=Ref(y1), ldx=192, in_scale=Ref(sc2), in_shift=Ref(sh2), in_relu=1, in_mask=None, in_mask_ld=0, dz=Ref(dz48), lddz=48, dw=Ref(dw2), ksplit=0)),
 }
+dwg = [torch.zeros(192*CIN, device=dev) for _ in range(4)]
+def wgroup(nsrc, ks=0):
+    f = dict(n_img=n, H=H, W=W, cin=CIN, cout=192, taps=1, dil=1, x=Ref(slab), ldx=LD, in_scale=Ref(sc1), in_shift=Ref(sh1), in_relu=1, in_mask=None,
+             in_mask_ld=0, dz=Ref(y1), lddz=192, dw=Ref(dwg[0]), ksplit=ks, n_src=nsrc)
+    for k, yk in list(enumerate((y1, y1b, y1c, y1d)))[1:nsrc]:
+        f.update({'dz%d' % k: Ref(yk), 'dw%d' % k: Ref(dwg[k]), 'sc%d' % k: Ref(sc1), 'sh%d' % k: Ref(sh1), 'cin%d' % k: CIN - 48 * k})
+    return ('wgrad', f)
+for ns in (2, 3, 4):
+    cases['wgroup%d' % ns] = wgroup(ns)
 for dbg in (2, 4, 8, 6):
     kind, f = cases['fwd3x3']; f = dict(f); f['in_mask_ld'] = dbg; cases['fwd3x3_dbg%d' % dbg] = (kind, f)
 for ks in (25, 38, 51, 76):
@@ -74,7 +83,7 @@ for name, (kind, f) in cases.items():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); prog.run(); e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1)*1e3/a.iters
-    fl = 2.0*M*f['cout']*f['taps']*f['cin']*max(1, f.get('n_src', 0))
+    fl = 2.0*M*f['cout']*f['taps']*(sum([f['cin']] + [f['cin%d' % k] for k in range(1, f['n_src'])]) if kind == 'wgrad' and f.get('n_src', 0) > 1 else f['cin']*max(1, f.get('n_src', 0)))
     print('%-14s %9.1f us  %7.1f TFLOP/s' % (name, us, fl/us/1e6), flush=True)
 
 # ---- do two different kernels overlap when they run on two streams?  (python tools_conv_bench.py --only overlap)
