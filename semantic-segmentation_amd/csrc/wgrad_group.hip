@@ -31,6 +31,10 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef WGG_ABL
+#define WGG_ABL 0                // diagnostic builds (timing only, results wrong): 1 no fragment reads / MFMA, 2 no x prologue / LDS
+                                 // store, 3 no dz DMA, 4 no x DMA, 5 no barrier
+#endif
 #ifndef WGG_XPOLICY
 #define WGG_XPOLICY ""           // cache policy suffix of the x stream (read once per launch): "" or " nt"
 #endif
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_group_kernel(const WGArgs a) {
         const uint32_t slot_l = zring_l + (uint32_t)(d_stage % NZ) * Z_BYTES;
 #pragma unroll
         for (int t = 0; t < Z_PER_WAVE; ++t) {
-            if (t * NW + wave < Z_INSTR) {
+            if (WGG_ABL != 3 && t * NW + wave < Z_INSTR) {
                 int m = m0 + (int)(zd[t] >> 16);
                 m = m < M ? m : M - 1;
                 const uint32_t off = (uint32_t)m * (uint32_t)a.lddz * 2u + (zd[t] & 0xffffu);
@@ -167,11 +171,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad_group_kernel(const WGArgs a) {
         mb = mb < M ? mb : M - 1;
         const u16* pa = xg + (int64_t)ma * a.ldx;
         const u16* pb = xg + (int64_t)mb * a.ldx;
+        if (WGG_ABL == 4) return;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" WGG_XPOLICY : : "s"(xraw_l), "v"(pa) : "memory");
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" WGG_XPOLICY : : "s"(xraw_l + 1024u), "v"(pb) : "memory");
     };
     uint4 xc0, xc1;                                      // raw x rows of the current K-step
     auto store_x = [&](const int s, const int step, const uint4& x0, const uint4& x1, unsigned char* Xs) {
+        if (WGG_ABL == 2) return;
         float sc[8], sh[8];
         load8f(tab + s * 2 * BC + xc * 8, sc);
         load8f(tab + s * 2 * BC + BC + xc * 8, sh);
@@ -205,16 +211,20 @@ __global__ __launch_bounds__(NT, 2) void wgrad_group_kernel(const WGArgs a) {
 
     auto mma = [&](f32x4 (&ac)[MQ][MC], const unsigned char* Zs, const unsigned char* Xs) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < (WGG_ABL == 1 ? 0 : 2); ++ks) {
             bf16x8 zf[MQ];
 #pragma unroll
             for (int i = 0; i < MQ; ++i) zf[i] = tr_frag(Zs + zfrag + (ks * 32 * ZS + i * 16) * 2, 4 * ZS * 2);
+            // the x fragment of column block j + 1 is requested before the MFMAs of block j are issued
+            bf16x8 xf = tr_frag(Xs + xfrag + (ks * 32 * XS) * 2, 4 * XS * 2);
 #pragma unroll
             for (int j = 0; j < MC; ++j) {
-                const bf16x8 xf = tr_frag(Xs + xfrag + (ks * 32 * XS + j * 16) * 2, 4 * XS * 2);
+                bf16x8 xn = xf;
+                if (j + 1 < MC) xn = tr_frag(Xs + xfrag + (ks * 32 * XS + (j + 1) * 16) * 2, 4 * XS * 2);
 #pragma unroll
                 for (int i = 0; i < MQ; ++i)
                     ac[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[i], xf, ac[i][j], 0, 0, 0);
+                xf = xn;
             }
         }
     };
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_group_kernel(const WGArgs a) {
         // written; after the barrier that holds for every wave, and every wave is done reading the previous stage's
         // buffers, so the ring slot of the previous stage takes the tile three stages ahead
         wait_vm<2 * ZMIN>();
-        __builtin_amdgcn_s_barrier();
+        if (WGG_ABL != 5) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         issue_z();
         issue_x(k + 1);                                          // past the last K-step: the last one again, never used
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_group_kernel(const WGArgs a) {
         for (int s = 1; s < NSRC; ++s) {
             if (s < nact) {
                 wait_vm<2 * ZMIN + 2>();
-                __builtin_amdgcn_s_barrier();
+                if (WGG_ABL != 5) __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 issue_z();
                 mma(acc[s], zring + (stage % NZ) * Z_BYTES, xbuf + (stage & 1) * X_BYTES);
