@@ -1,0 +1,238 @@
+"""-m gpu: the benchmark configurations that are too large for the fp32 oracle, checked through properties that do
+not depend on size, plus kernels at the far end of their address range.
+
+  * DenseASPP201 training at 1024x2048 (deepest dense blocks): finite gradients, Adam steps reduce the loss, BatchNorm
+    batch counters advance, the eval-mode forward is independent of batch neighbours;
+  * DenseASPP169 inference at 512x1024 / 1024x2048 / 2048x4096 (dilation halos on a 256x512 map, slabs past 2^31
+    bytes per batch): batch independence, the three output forms agree, confusion counts are conserved, and at
+    2048x4096 the bf16 form is compared with the fp32 form of the same network (2e-2 of the largest logit) so that
+    what is computed at the far end of the buffers is checked, not just that nothing faulted;
+  * DenseASPP161 (the benchmark network) against the oracle at 128x256;
+  * the streaming 1x1 forward and the grouped slab data gradient on a slab larger than 4 GiB: the rows at the end of
+    the slab must equal what the same kernel computes for those rows alone.
+"""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from optools import Ref  # noqa: E402
+
+
+def _batch(B, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 3, H, W, generator=g).clamp_(-2.2, 2.7)
+    labels = torch.randint(0, 19, (B, H, W), generator=g)
+    labels[torch.rand(B, H, W, generator=g) < 0.1] = 255
+    return x.cuda(), labels.cuda()
+
+
+def _free(model):
+    model._engines.clear()
+    torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------ DenseASPP201, training at 1024x2048
+def test_densenet201_training_fullsize():
+    import denseASPP
+    from cfgs import DenseASPP201
+    from semantic_segmentation_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    m = denseASPP.DenseASPP(DenseASPP201.Model_CFG, n_class=19, output_stride=8).cuda().train()
+    assert m.spec.blocks[2].C == 1792 and m.spec.blocks[3].C == 1920          # 48 and 32 layers deep
+    opt = FusedAdam(m, lr=1e-4, weight_decay=1e-4)
+    x, labels = _batch(2, 1024, 2048, 21)
+    gen = torch.Generator(device='cuda').manual_seed(6)
+    nbt0 = int(m.features.norm0.num_batches_tracked)
+    losses = []
+    for _ in range(5):
+        loss = m.train_step(x, labels, generator=gen)
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+        assert float(max(p.grad.abs().max() for p in m.parameters())) > 0
+        opt.step()
+        losses.append(float(loss))
+    print('DenseASPP201 full-size training losses:', ['%.4f' % l for l in losses])
+    assert all(l == l and l < 20 for l in losses), losses
+    assert losses[-1] < losses[0], losses
+    assert abs(losses[0] - 2.944) < 0.8, losses          # near ln(19) at random initialisation
+    assert int(m.features.norm0.num_batches_tracked) == nbt0 + 5
+    _free(m)
+    m.eval()
+    with torch.no_grad():
+        both = m.forward_lowres(x)
+        one1 = m.forward_lowres(x[1:])
+    assert torch.isfinite(both).all() and torch.equal(both[1:], one1)
+    _free(m)
+
+
+# ------------------------------------------------------------------ DenseASPP169, inference sweep
+@pytest.fixture(scope='module')
+def model169():
+    import denseASPP
+    from cfgs import DenseASPP169
+    torch.manual_seed(0)
+    m = denseASPP.DenseASPP(DenseASPP169.Model_CFG, n_class=19, output_stride=8).cuda().eval()
+    # random initialisation gives nearly tied classes: widen the margins so that arg-max comparisons mean something
+    with torch.no_grad():
+        m.classification[1].weight.mul_(8.0)
+    yield m
+    _free(m)
+
+
+@pytest.mark.parametrize('H,W,B', [(512, 1024, 3), (1024, 2048, 2), (2048, 4096, 2)])
+def test_densenet169_inference_sweep(model169, H, W, B):
+    from semantic_segmentation_amd import eval_ops
+    m = model169
+    x, labels = _batch(B, H, W, 31 + H)
+    with torch.no_grad():
+        both = m.forward_lowres(x)
+        again = m.forward_lowres(x)
+        last = m.forward_lowres(x[B - 1:])
+    assert torch.isfinite(both).all()
+    assert torch.equal(both, again)
+    assert torch.equal(both[B - 1:], last)               # the image at the END of the batch buffers, alone
+    _free(m)
+    x1, l1 = x[B - 1:], labels[B - 1:]
+    with torch.no_grad():
+        full = m(x1)
+        am = m.predict(x1)
+        conf, am2 = eval_ops.confusion_matrix(m, x1, l1, return_argmax=True)
+    assert full.shape == (1, 19, H, W) and am.shape == (1, H, W)
+    assert torch.equal(am, am2)
+    top2 = full.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4 * float(full.abs().max())
+    assert bool((am == full.argmax(1))[clear].all()) and float(clear.float().mean()) > 0.99
+    assert int(conf.sum()) == H * W
+    assert int(conf[19].sum()) == int((l1 == 255).sum())
+    assert torch.equal(conf[:19].sum(1), torch.bincount(l1[l1 != 255].flatten(), minlength=19))
+    assert torch.equal(conf.sum(0), torch.bincount(am.flatten(), minlength=19))
+    _free(m)
+
+
+def test_densenet169_bf16_vs_fp32_form_at_2048x4096(model169):
+    """The fp32 form of the network (fp32 storage, fp32 MFMA, checked against the oracle to 1e-4 at small sizes) is
+    the yardstick where the oracle cannot go: bf16 logits within 2e-2 of the largest logit and arg-max agreement on
+    every pixel whose fp32 margin exceeds that error budget, on a 256x512 feature map."""
+    m = model169
+    H, W = 2048, 4096
+    x, _ = _batch(1, H, W, 77)
+    with torch.no_grad():
+        y16 = m.forward_lowres(x).float()
+    _free(m)
+    m.set_compute_dtype(torch.float32)
+    try:
+        with torch.no_grad():
+            y32 = m.forward_lowres(x).float()
+    finally:
+        m.set_compute_dtype(torch.bfloat16)
+        _free(m)
+    scale = float(y32.abs().max())
+    err = float((y16 - y32).abs().max()) / scale
+    print('DenseASPP169 2048x4096: bf16 vs fp32 form, max|d|/max|ref| = %.3e' % err)
+    assert err < 2e-2
+    # the bottom-right corner of the map lies at the far end of every buffer
+    corner = float((y16[..., -8:, -8:] - y32[..., -8:, -8:]).abs().max()) / scale
+    assert corner < 2e-2
+    top2 = y32.topk(2, dim=1).values
+    clearpx = (top2[:, 0] - top2[:, 1]) > 2 * 2e-2 * scale
+    same = y16.argmax(1) == y32.argmax(1)
+    assert float(clearpx.float().mean()) > 0.3 and bool(same[clearpx].all())
+
+
+# ------------------------------------------------------------------ DenseASPP161 against the oracle
+def test_eval_forward_densenet161_matches_oracle():
+    from cfgs import DenseASPP161
+    from e2e_common import make_batch, make_pair
+    ref, mod = make_pair(DenseASPP161.Model_CFG, randomize_bn=False)
+    with torch.no_grad():
+        ref.classification[1].weight.mul_(8.0)
+    mod.load_state_dict(ref.state_dict())
+    x, _ = make_batch(1, 128, 256)
+    ref.eval()
+    mod = mod.cuda().eval()
+    with torch.no_grad():
+        yr = ref(x)
+        ym = mod(x.cuda()).cpu()
+    err = float((yr - ym).abs().max() / yr.abs().max())
+    print('DenseASPP161 128x256 bf16 logits vs oracle: %.3e' % err)
+    assert err < 2e-2                                    # bf16 budget of the north star
+    top2 = yr.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2 * 2e-2 * float(yr.abs().max())
+    same = ym.argmax(1) == yr.argmax(1)
+    assert float(same[clear].float().mean()) >= 0.999
+    mod.set_compute_dtype(torch.float32)
+    with torch.no_grad():
+        y32 = mod(x.cuda()).cpu()
+    err32 = float((yr - y32).abs().max() / yr.abs().max())
+    print('DenseASPP161 128x256 fp32 logits vs oracle: %.3e' % err32)
+    assert err32 < 1e-4                                  # fp32 budget of the north star
+
+
+# ------------------------------------------------------------------ kernels on a slab larger than 4 GiB
+_CONV = dict(in_scale=None, in_shift=None, in_relu=0, in_mask=None, in_mask_ld=0, bias=None, out_mask=None, out_mask_ld=0,
+             y=None, ldy=0, y_f32=0, stat_acc=None, epi_relu=0, ref=None, ldref=0, e_scale=None, e_shift=None, e_mean=None,
+             e_rstd=None, s_acc=None, g=None, ldg=0, g_accumulate=0, g_bf16=0)
+
+
+def _big_slab(M, LD, seed):
+    """bf16 [M][LD] of pseudo-random values built block-wise (a 4 GiB randn in fp32 would need 9 GiB of staging)."""
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    slab = torch.empty(M * LD, dtype=torch.bfloat16, device='cuda')
+    step = 1 << 26
+    for o in range(0, slab.numel(), step):
+        n = min(step, slab.numel() - o)
+        slab[o:o + n] = torch.randn(n, device='cuda', generator=g).to(torch.bfloat16)
+    return slab
+
+
+def test_kernels_on_a_slab_past_4GiB():
+    from semantic_segmentation_amd.backend import HipBackend
+    be = HipBackend()
+    H, W, n = 1024, 1024, 1
+    M, LD, CIN, MID = n * H * W, 2112, 2064, 192
+    assert M * LD * 2 > (1 << 32)
+    slab = _big_slab(M, LD, 5)
+    g = torch.Generator(device='cuda').manual_seed(9)
+    sc = torch.rand(LD, device='cuda', generator=g) + 0.5
+    sh = torch.randn(LD, device='cuda', generator=g) * 0.3
+    w = (torch.randn(MID * CIN, device='cuda', generator=g) * CIN ** -0.5).to(torch.bfloat16)
+    tail = 8 * W                                         # the last 8 image rows, run again as a problem of their own
+    off = (M - tail) * LD
+
+    # ---- streaming BN-ReLU-1x1 forward: x rows at byte offsets past 2^32
+    y = torch.zeros(M * MID, dtype=torch.bfloat16, device='cuda')
+    y_t = torch.zeros(tail * MID, dtype=torch.bfloat16, device='cuda')
+    f = dict(_CONV, n_img=n, H=H, W=W, cin=CIN, cout=MID, taps=1, dil=1, x=Ref(slab), ldx=LD, w=Ref(w), in_scale=Ref(sc),
+             in_shift=Ref(sh), in_relu=1, y=Ref(y), ldy=MID)
+    be.call('conv', **f)
+    be.call('conv', **dict(f, H=8, x=Ref(slab, off), y=Ref(y_t)))
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all()
+    assert float(y_t.float().abs().max()) > 0
+    assert torch.equal(y[(M - tail) * MID:], y_t)
+
+    # ---- grouped slab data gradient (two sources): reference rows and gradient-slab rows past 2^32
+    dy = [(torch.randn(M * MID, device='cuda', generator=g)).to(torch.bfloat16) for _ in range(2)]
+    wt = [(torch.randn(CIN * MID, device='cuda', generator=g) * MID ** -0.5).to(torch.bfloat16) for _ in range(2)]
+    es = [torch.rand(CIN, device='cuda', generator=g) + 0.5 for _ in range(2)]
+    eh = [torch.randn(CIN, device='cuda', generator=g) * 0.3 for _ in range(2)]
+    mean = torch.randn(CIN, device='cuda', generator=g) * 0.1
+    rstd = torch.rand(CIN, device='cuda', generator=g) + 0.5
+    gs = torch.zeros(M * LD, dtype=torch.bfloat16, device='cuda')
+    gs_t = torch.zeros(tail * LD, dtype=torch.bfloat16, device='cuda')
+    acc = [torch.zeros(16 * 2 * CIN, device='cuda') for _ in range(2)]
+    d = dict(_CONV, n_img=n, H=H, W=W, cin=MID, cout=CIN, taps=1, dil=1, x=Ref(dy[0]), ldx=MID, w=Ref(wt[0]), epi_relu=1,
+             ref=Ref(slab), ldref=LD, e_scale=Ref(es[0]), e_shift=Ref(eh[0]), e_mean=Ref(mean), e_rstd=Ref(rstd),
+             s_acc=Ref(acc[0]), g=Ref(gs), ldg=LD, g_accumulate=0, g_bf16=1, n_src=2, x1=Ref(dy[1]), w1=Ref(wt[1]),
+             es1=Ref(es[1]), eh1=Ref(eh[1]), sa1=Ref(acc[1]))
+    be.call('conv', **d)
+    be.call('conv', **dict(d, H=8, x=Ref(dy[0], (M - tail) * MID), x1=Ref(dy[1], (M - tail) * MID), ref=Ref(slab, off),
+                           g=Ref(gs_t)))
+    torch.cuda.synchronize()
+    got = gs.view(M, LD)[M - tail:, :CIN]
+    want = gs_t.view(tail, LD)[:, :CIN]
+    assert torch.isfinite(got.float()).all() and float(want.float().abs().max()) > 0
+    assert torch.equal(got, want)
+    assert bool((gs.view(M, LD)[M - tail:, CIN:] == 0).all())        # channels past cout untouched
