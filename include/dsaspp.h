@@ -34,6 +34,9 @@ typedef void* dsaspp_stream_t; /* hipStream_t */
 #define DSASPP_STAT_REPLICAS 16 /* per-channel sums are spread over this many replica rows */
 
 int dsaspp_version(void);
+/* Hash (16 hex digits) of the source files this library was built from, as semantic-segmentation_amd/build.py computes it
+ * for the tree: lets a prebuilt library be matched to a checkout (measurement records carry it). */
+const char* dsaspp_source_hash(void);
 const char* dsaspp_last_error(void);
 
 /* ------------------------------------------------------------------------------------

@@ -144,6 +144,7 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.dsaspp_last_error.restype = ctypes.c_char_p
     lib.dsaspp_version.restype = ctypes.c_int
+    lib.dsaspp_source_hash.restype = ctypes.c_char_p
     for _, (_, struct, entry) in OPS.items():
         if entry is not None:
             fn = getattr(lib, entry)
@@ -172,6 +173,11 @@ def load():
                                                ctypes.POINTER(ctypes.c_int64)]
     _lib = lib
     return lib
+
+
+def source_hash():
+    """Hash of the sources the loaded library was built from (dsaspp_source_hash)."""
+    return load().dsaspp_source_hash().decode()
 
 
 def check(rc):

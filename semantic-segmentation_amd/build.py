@@ -18,10 +18,32 @@ def _hipcc():
     return 'hipcc'
 
 
+def source_hash():
+    """sha256 over every file the library is compiled from (kernel sources, shared header, public header), in a fixed
+    order: what dsaspp_source_hash() of a library built from this tree returns."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'common.h'), os.path.join(INCLUDE, 'dsaspp.h')]:
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def library_hash():
+    """The source hash baked into the built library, read without loading it (None if absent)."""
+    if not os.path.exists(LIB):
+        return None
+    import re
+    m = re.search(rb'DSASPP_SRC=([0-9a-f]{16})', open(LIB, 'rb').read())
+    return m.group(1).decode() if m else None
+
+
 def build_library(force=False, verbose=False, extra_flags=()):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(INCLUDE, 'dsaspp.h'), os.path.abspath(__file__)]
-    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
+    sh = source_hash()
+    # rebuilt whenever the sources differ from what the library was built from (not by modification time: a
+    # checkout or a copy changes times, and a stale prebuilt library would go unnoticed)
+    if not force and library_hash() == sh and not extra_flags:
         return LIB
     objs = []
     procs = []
@@ -30,6 +52,8 @@ def build_library(force=False, verbose=False, extra_flags=()):
         objs.append(obj)
         cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', INCLUDE, '-I', CSRC,
                '-Wall', '-Wno-unused-function', *extra_flags, '-c', src, '-o', obj]
+        if src.endswith('program.hip'):
+            cmd.insert(-4, '-DDSASPP_SOURCE_HASH="%s"' % sh)
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

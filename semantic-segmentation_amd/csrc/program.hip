@@ -17,7 +17,13 @@ int dsaspp_set_error(const char* fmt, ...) {
     return 1;
 }
 
-extern "C" int dsaspp_version(void) { return 1; }
+extern "C" int dsaspp_version(void) { return 2; }
+#ifndef DSASPP_SOURCE_HASH
+#define DSASPP_SOURCE_HASH "unknown"
+#endif
+// the marker in front makes the hash findable in the file without loading it
+static const char g_source_hash[] = "DSASPP_SRC=" DSASPP_SOURCE_HASH;
+extern "C" const char* dsaspp_source_hash(void) { return g_source_hash + 11; }
 extern "C" const char* dsaspp_last_error(void) { return g_err; }
 
 namespace {

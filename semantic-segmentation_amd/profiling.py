@@ -61,14 +61,29 @@ def kernel_class(kind, f):
 
 
 def work(kind, f):
-    """(flops, bytes) of one launch: algorithmic, i.e. what the operation needs, not what a kernel moves."""
-    if kind == 'wgrad' and (f.get('n_src') or 0) > 1:
+    """(flops, bytes) of one launch: algorithmic, i.e. what the operation needs when every operand is moved once (each
+    input tensor read once, each output written once, a gradient slab that is accumulated into read and written),
+    not what a kernel moves."""
+    if kind == 'wgrad':
         M = f['n_img'] * f['H'] * f['W']
-        k = f['cin'] + sum(f['cin%d' % i] for i in range(1, f['n_src']))
-        return 2.0 * M * f['cout'] * k, 0.0
-    if kind in ('conv', 'wgrad'):
+        n = max(1, f.get('n_src') or 0)
+        cins = [f['cin']] + [f['cin%d' % i] for i in range(1, n)]
+        k = sum(cins) * f['taps']
+        # the shared input once, one dz per source, fp32 weight gradients out
+        return 2.0 * M * f['cout'] * k, 2.0 * M * max(cins) + 2.0 * M * f['cout'] * n + 4.0 * f['cout'] * k
+    if kind == 'conv':
         M = f['n_img'] * f['H'] * f['W']
-        return 2.0 * M * f['cout'] * f['taps'] * f['cin'] * max(1, f.get('n_src') or 0), 0.0
+        n = max(1, f.get('n_src') or 0)
+        esz = 4.0 if f.get('dtype') else 2.0
+        by = esz * M * f['cin'] * n + esz * f['cout'] * f['taps'] * f['cin'] * n
+        if f.get('ref') is not None:
+            by += 2.0 * M * f['cout']
+        if f.get('g') is not None:
+            gsz = 2.0 if f.get('g_bf16') else 4.0
+            by += gsz * M * f['cout'] * (2 if f.get('g_accumulate') else 1)
+        else:
+            by += (4.0 if f.get('y_f32') else esz) * M * f['cout']
+        return 2.0 * M * f['cout'] * f['taps'] * f['cin'] * n, by
     if kind == 'upce':
         m = f['n_img'] * f['h'] * f['w']
         # fp32 low-res logits read (n_class), int64 labels read, fp32 low-res gradient written

@@ -66,3 +66,14 @@ def test_new_entry_points_validate_without_gpu():
     p.n_img, p.H, p.W = 1, 4, 6                                           # width not a multiple of 4
     assert lib.dsaspp_preprocess(ctypes.byref(p), None) != 0
     assert b'multiple of 4' in lib.dsaspp_last_error()
+
+
+def test_library_was_built_from_this_tree():
+    """The in-tree library carries the hash of its sources; a stale prebuilt binary must not pass for the current code."""
+    import importlib.util
+    import os
+    from semantic_segmentation_amd import _lib
+    spec = importlib.util.spec_from_file_location('dsaspp_build', os.path.join(os.path.dirname(_lib.HERE), 'semantic-segmentation_amd', 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert _lib.source_hash() == mod.source_hash() == mod.library_hash()

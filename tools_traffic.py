@@ -33,6 +33,7 @@ for k in sorted(set(fetch) | set(write)):
     f = sum(fetch[k]) / max(len(fetch[k]), 1); w = sum(write[k]) / max(len(write[k]), 1)
     out[k] = dict(fetch_kib=round(f, 1), write_kib=round(w, 1), hbm_bytes_per_launch=int((2 * f + w) * 1024), launches=len(fetch[k]))
 if len(sys.argv) > 4:      # per-GPU batch of the profiled bench.py run: bench.py reports the traffic only for that batch
-    out['_meta'] = dict(batch=int(sys.argv[4]))
+    from semantic_segmentation_amd import _lib
+    out['_meta'] = dict(batch=int(sys.argv[4]), source_hash=_lib.source_hash())
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print(json.dumps(out, indent=1))
