@@ -14,9 +14,11 @@
  * layer can read or write a channel slice of a wider feature slab; bf16 unless stated.
  * Descriptors with a `dtype` field also have an fp32 form (dtype = 1): activations AND the
  * weights they are multiplied with are then fp32 (weights straight from the fp32 master
- * arena, same [cout][taps][cin] layout), arithmetic is fp32 throughout.  That form covers the
- * eval-mode forward pass only (no statistics, no gradient epilogues) and exists so that the
- * network can be checked against an fp32 reference to 1e-4.
+ * arena, same [cout][taps][cin] layout), arithmetic is fp32 throughout.  That form exists so that
+ * the network can be checked against an fp32 reference (logits to 1e-4, gradients to 1e-3): it
+ * covers the forward pass of both trunks and the training pass (statistics, gradient epilogues,
+ * weight gradients, BatchNorm backward) of the DenseNet trunks at output stride 8, with plain
+ * untuned kernels.
  * Convolution weights are bf16 [cout][taps][cin] (K contiguous).  Channel counts, channel
  * offsets and strides must be multiples of 8 (16-byte chunks).
  */
@@ -136,6 +138,7 @@ typedef struct dsaspp_wgrad_desc {
     const void* dz1; float* dw1; const float* sc1; const float* sh1; int32_t cin1;
     const void* dz2; float* dw2; const float* sc2; const float* sh2; int32_t cin2;
     const void* dz3; float* dw3; const float* sc3; const float* sh3; int32_t cin3;
+    int32_t dtype;            /* storage type of x and dz: 0 = bf16 (default), 1 = fp32 */
 } dsaspp_wgrad_desc;
 
 int dsaspp_conv_wgrad(const dsaspp_wgrad_desc* d, dsaspp_stream_t stream);
@@ -239,6 +242,7 @@ typedef struct dsaspp_gradx_desc {
     int32_t dz_f32;           /* store dz as fp32 (when it feeds a BatchNorm backward: see bn_bwd_apply) */
     float* s_acc;
     float* colsum;
+    int32_t dtype;            /* 0 = bf16 activations (default); 1 = fp32: g, xs, yref and dz are all fp32 */
 } dsaspp_gradx_desc;
 int dsaspp_grad_extract(const dsaspp_gradx_desc* d, dsaspp_stream_t stream);
 
@@ -252,6 +256,7 @@ typedef struct dsaspp_bnapply_desc {
     const float* coefA; const float* coefB; const float* coefC;
     void* dy; int32_t lddy;
     float* colsum;
+    int32_t dtype;            /* 0 = bf16 activations (default); 1 = fp32: dr, y and dy are all fp32 */
 } dsaspp_bnapply_desc;
 int dsaspp_bn_bwd_apply(const dsaspp_bnapply_desc* d, dsaspp_stream_t stream);
 
@@ -505,6 +510,9 @@ typedef struct dsaspp_wt_entry {
 } dsaspp_wt_entry;
 int dsaspp_weight_transpose(const void* src, void* dst, const dsaspp_wt_entry* table_dev,
                             int32_t n_entries, int64_t max_elems, dsaspp_stream_t stream);
+/* same for fp32 arenas (the fp32 form of the data-gradient convolutions) */
+int dsaspp_weight_transpose_f32(const float* src, float* dst, const dsaspp_wt_entry* table_dev,
+                                int32_t n_entries, int64_t max_elems, dsaspp_stream_t stream);
 
 /* fp32 2-D strided copy (row pad / unpad of the stem weight and its gradient);
  * dst[r][c] = src[r][c] (+= when accumulate) for c < cols; dst columns [cols, dst_cols) are zeroed. */

@@ -156,6 +156,8 @@ def load():
     lib.dsaspp_cast_bf16.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
     lib.dsaspp_weight_transpose.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
                                             ctypes.c_int64, ctypes.c_void_p]
+    lib.dsaspp_weight_transpose_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                                ctypes.c_int64, ctypes.c_void_p]
     lib.dsaspp_copy2d_f32.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
     lib.dsaspp_copy2d_f32_bf16.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,

@@ -52,7 +52,7 @@ class HipBackend:
     """Runs descriptor lists through libdsaspp.so.  There is no other compute backend in the package."""
     stat_replicas = _lib.STAT_REPLICAS
     act_dtype = torch.bfloat16
-    forward_only_fp32 = True      # the fp32 kernels implement the eval-mode forward pass only
+    forward_only_fp32 = True      # fp32 storage: kernels read the fp32 master weights; training only for DenseNet trunks at OS 8
 
     def __init__(self, act_dtype=torch.bfloat16):
         if act_dtype not in (torch.bfloat16, torch.float32):
@@ -82,6 +82,21 @@ class HipBackend:
         _lib.check(getattr(self.lib, entry)(ctypes.byref(d), ctypes.c_void_p(stream)))
 
     # ------------------------------------------------------------------ weight shadows
+    @staticmethod
+    def _wt_table(model):
+        """Device table of (source offset, destination offset, shape) of every convolution weight, built once."""
+        if model._wt_table is None:
+            ents = [e for e in model.arena.entries if e.kind == 'conv']
+            tab = (_lib.wt_entry * len(ents))()
+            mx = 0
+            for i, e in enumerate(ents):
+                tab[i].src_off, tab[i].dst_off = e.off, e.toff
+                tab[i].cout, tab[i].cin, tab[i].taps = e.rows, e.cin, e.taps
+                mx = max(mx, e.numel)
+            raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).clone()
+            model._wt_table = (raw.to(model._flat.device), len(ents), mx)
+        return model._wt_table
+
     def refresh_weights(self, model, cast=True):
         """fp32 arena -> bf16 shadow (same offsets), padded stem rows, transposed copies for the dgrad convs."""
         from . import spec as S
@@ -95,6 +110,10 @@ class HipBackend:
             if e0 is not None:
                 _lib.check(lib.dsaspp_copy2d_f32(model._flat.data_ptr() + 4 * e0.off, S.STEM_K, model._w0_16.data_ptr(),
                                                  S.STEM_KPAD, e0.rows, S.STEM_K, S.STEM_KPAD, 0, stream))
+            # transposed fp32 copies for the data-gradient convolutions of the fp32 training form
+            tab_dev, n, mx = self._wt_table(model)
+            _lib.check(lib.dsaspp_weight_transpose_f32(model._flat.data_ptr(), model._wt16.data_ptr(), tab_dev.data_ptr(), n, mx,
+                                                       stream))
             return
         if cast:
             _lib.check(lib.dsaspp_cast_bf16(model._flat.data_ptr(), model._w16.data_ptr(), ar.size, stream))
@@ -102,16 +121,6 @@ class HipBackend:
         if e0 is not None:      # 7x7 stem of the DenseNet trunk: rows padded 147 -> 160 for the im2col GEMM
             _lib.check(lib.dsaspp_copy2d_f32_bf16(model._flat.data_ptr() + 4 * e0.off, S.STEM_K, model._w0_16.data_ptr(),
                                                   S.STEM_KPAD, e0.rows, S.STEM_K, S.STEM_KPAD, stream))
-        if model._wt_table is None:
-            ents = [e for e in ar.entries if e.kind == 'conv']
-            tab = (_lib.wt_entry * len(ents))()
-            mx = 0
-            for i, e in enumerate(ents):
-                tab[i].src_off, tab[i].dst_off = e.off, e.toff
-                tab[i].cout, tab[i].cin, tab[i].taps = e.rows, e.cin, e.taps
-                mx = max(mx, e.numel)
-            raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).clone()
-            model._wt_table = (raw.to(model._flat.device), len(ents), mx)
-        tab_dev, n, mx = model._wt_table
+        tab_dev, n, mx = self._wt_table(model)
         _lib.check(lib.dsaspp_weight_transpose(model._w16.data_ptr(), model._wt16.data_ptr(), tab_dev.data_ptr(), n, mx,
                                                stream))

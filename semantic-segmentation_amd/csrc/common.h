@@ -32,6 +32,12 @@ int dsaspp_f32_im2col(const dsaspp_im2col_desc& d, hipStream_t s);
 int dsaspp_f32_maxpool(const dsaspp_maxpool_desc& d, hipStream_t s);
 int dsaspp_f32_stem3(const dsaspp_stem3_desc& d, hipStream_t s);
 int dsaspp_f32_dwconv(const dsaspp_dw_desc& d, hipStream_t s);
+// training side of the fp32 form (DenseNet trunks)
+int dsaspp_f32_wgrad(const dsaspp_wgrad_desc& d, hipStream_t s);
+int dsaspp_f32_grad_extract(const dsaspp_gradx_desc& d, hipStream_t s);
+int dsaspp_f32_bn_bwd_apply(const dsaspp_bnapply_desc& d, hipStream_t s);
+int dsaspp_f32_avgpool_bwd(const dsaspp_pool_desc& d, hipStream_t s);
+int dsaspp_f32_maxpool_bwd(const dsaspp_maxpool_desc& d, hipStream_t s);
 
 #define DS_REQUIRE(cond, ...)                                  \
     do {                                                       \

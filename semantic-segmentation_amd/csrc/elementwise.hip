@@ -533,6 +533,7 @@ extern "C" int dsaspp_grad_extract(const dsaspp_gradx_desc* d, dsaspp_stream_t s
     if (d->relu || d->s_acc) DS_REQUIRE(d->yref && d->ldyref % 8 == 0, "grad_extract: yref missing");
     if (d->s_acc) DS_REQUIRE(d->r_mean && d->r_rstd, "grad_extract: r_mean/r_rstd missing");
     if (d->mask) DS_REQUIRE(d->hw > 0 && d->mask_ld % 4 == 0, "grad_extract: mask needs hw");
+    if (d->dtype == 1) return dsaspp_f32_grad_extract(*d, (hipStream_t)stream);
     ROW_DISPATCH(grad_extract_kernel, d->C, d->M, *d, (hipStream_t)stream);
     DS_LAUNCH_CHECK("grad_extract");
     return 0;
@@ -541,6 +542,7 @@ extern "C" int dsaspp_grad_extract(const dsaspp_gradx_desc* d, dsaspp_stream_t s
 extern "C" int dsaspp_bn_bwd_apply(const dsaspp_bnapply_desc* d, dsaspp_stream_t stream) {
     DS_REQUIRE(d && d->M > 0 && d->C > 0 && d->C % 8 == 0 && d->lddr % 8 == 0 && d->ldy % 8 == 0 && d->lddy % 8 == 0, "bn_bwd_apply: bad descriptor");
     DS_REQUIRE(d->dr && d->y && d->dy && d->coefA && d->coefB && d->coefC, "bn_bwd_apply: null tensor");
+    if (d->dtype == 1) return dsaspp_f32_bn_bwd_apply(*d, (hipStream_t)stream);
     if (!d->colsum && d->lddr == d->C && d->ldy == d->C && d->lddy == d->C &&
         (((uintptr_t)d->dr | (uintptr_t)d->y | (uintptr_t)d->dy) & 15) == 0) {
         const int CG = d->C / 8;
@@ -575,6 +577,7 @@ extern "C" int dsaspp_avgpool2_bwd(const dsaspp_pool_desc* d, dsaspp_stream_t st
     DS_REQUIRE(d && d->n_img > 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0, "avgpool2_bwd: H and W must be even");
     DS_REQUIRE(d->C > 0 && d->C % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->x && d->y, "avgpool2_bwd: bad descriptor");
     const int64_t Mi = (int64_t)d->n_img * d->H * d->W;
+    if (d->dtype == 1) return dsaspp_f32_avgpool_bwd(*d, (hipStream_t)stream);
     ROW_DISPATCH(avgpool_bwd_kernel, d->C, Mi, *d, (hipStream_t)stream);
     DS_LAUNCH_CHECK("avgpool2_bwd");
     return 0;
@@ -607,6 +610,7 @@ extern "C" int dsaspp_maxpool3s2_bwd(const dsaspp_maxpool_desc* d, dsaspp_stream
     DS_REQUIRE(d->C > 0 && d->C % 8 == 0 && d->ldx % 8 == 0 && d->lddy % 8 == 0 && d->lddr % 8 == 0, "maxpool3s2_bwd: bad strides");
     DS_REQUIRE(d->x && d->dy && d->dr && d->argmax && d->scale && d->shift && d->mean && d->rstd, "maxpool3s2_bwd: null tensor");
     const int64_t Mi = (int64_t)d->n_img * d->H * d->W;
+    if (d->dtype == 1) return dsaspp_f32_maxpool_bwd(*d, (hipStream_t)stream);
     ROW_DISPATCH(maxpool_bwd_kernel, d->C, Mi, *d, (hipStream_t)stream);
     DS_LAUNCH_CHECK("maxpool3s2_bwd");
     return 0;

@@ -48,11 +48,12 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* src, u16* dst, c
 }
 
 // dst[c][taps-1-t][n] = src[n][t][c]; one block row (blockIdx.y) per table entry
-__global__ __launch_bounds__(256) void wtrans_kernel(const u16* src, u16* dst, const dsaspp_wt_entry* table) {
+template <typename T>
+__global__ __launch_bounds__(256) void wtrans_kernel(const T* src, T* dst, const dsaspp_wt_entry* table) {
     const dsaspp_wt_entry e = table[blockIdx.y];
     const int64_t total = (int64_t)e.cout * e.cin * e.taps;
-    const u16* s = src + e.src_off;
-    u16* o = dst + e.dst_off;
+    const T* s = src + e.src_off;
+    T* o = dst + e.dst_off;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         // i indexes dst: [c][t'][n]
         const int n = (int)(i % e.cout);
@@ -113,9 +114,20 @@ extern "C" int dsaspp_weight_transpose(const void* src, void* dst, const dsaspp_
     DS_REQUIRE(n_entries <= 65535, "weight_transpose: too many entries");
     int64_t bx = (max_elems + 255) / 256;
     if (bx > 256) bx = 256;
-    hipLaunchKernelGGL(wtrans_kernel, dim3((unsigned)bx, (unsigned)n_entries), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(wtrans_kernel<u16>, dim3((unsigned)bx, (unsigned)n_entries), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const u16*>(src), reinterpret_cast<u16*>(dst), table_dev);
     DS_LAUNCH_CHECK("weight_transpose");
+    return 0;
+}
+
+extern "C" int dsaspp_weight_transpose_f32(const float* src, float* dst, const dsaspp_wt_entry* table_dev, int32_t n_entries,
+                                           int64_t max_elems, dsaspp_stream_t stream) {
+    DS_REQUIRE(src && dst && table_dev && n_entries > 0, "weight_transpose_f32: bad arguments");
+    int64_t bx = (max_elems + 255) / 256;
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(wtrans_kernel<float>, dim3((unsigned)bx, (unsigned)n_entries), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       table_dev);
+    DS_LAUNCH_CHECK("weight_transpose_f32");
     return 0;
 }
 

@@ -343,6 +343,8 @@ extern "C" int dsaspp_conv_wgrad(const dsaspp_wgrad_desc* dp, dsaspp_stream_t st
     DS_REQUIRE(((uintptr_t)d.x & 15) == 0 && ((uintptr_t)d.dz & 15) == 0, "conv_wgrad: operands must be 16-byte aligned");
     DS_REQUIRE((d.in_scale == nullptr) == (d.in_shift == nullptr), "conv_wgrad: in_scale/in_shift must come together");
     if (d.in_mask) DS_REQUIRE(d.in_mask_ld % 4 == 0, "conv_wgrad: in_mask_ld must be a multiple of 4");
+    DS_REQUIRE(d.dtype == 0 || d.dtype == 1, "conv_wgrad: dtype must be 0 (bf16) or 1 (fp32)");
+    if (d.dtype == 1) return dsaspp_f32_wgrad(d, s);
     if (d.n_src >= 2) return dsaspp_wgrad_group_launch(d, s);
     const int co = d.cout;
     if (co <= 32) return launch<32, 192, 1, 4>(d, s);

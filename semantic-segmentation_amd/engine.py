@@ -39,7 +39,8 @@ class Ref:
 
 
 # ops whose descriptor carries the activation storage type (include/dsaspp.h: `dtype`)
-_DTYPE_OPS = frozenset(('conv', 'bn_act', 'avgpool_fwd', 'im2col', 'maxpool_fwd', 'stem3', 'dwconv'))
+_DTYPE_OPS = frozenset(('conv', 'bn_act', 'avgpool_fwd', 'im2col', 'maxpool_fwd', 'stem3', 'dwconv', 'wgrad', 'grad_extract',
+                        'bn_bwd_apply', 'avgpool_bwd', 'maxpool_bwd'))
 
 
 class OpList(list):
@@ -98,9 +99,10 @@ class Engine:
         f32, bf16 = torch.float32, backend.act_dtype
         self.act_dtype = bf16
         self.dtype_code = 1 if backend.act_dtype == torch.float32 else 0
-        if self.dtype_code and training and getattr(backend, 'forward_only_fp32', False):
-            raise NotImplementedError('fp32 activation storage on the MI355X path covers eval-mode inference only; '
-                                      'train with the default bf16 storage')
+        if self.dtype_code and training and getattr(backend, 'forward_only_fp32', False) and (
+                model.spec.kind == 'mobilenet' or getattr(model.spec, 'output_stride', 8) != 8):
+            raise NotImplementedError('fp32 activation storage on the MI355X path trains the DenseNet trunks at output stride 8 '
+                                      'only; train this configuration with the default bf16 storage')
 
         def zeros(n, dt=f32):
             return torch.zeros(int(n), dtype=dt, device=dev)
@@ -552,7 +554,8 @@ class Engine:
         ce = dict(n_img=self.B, h=self.H2, w=self.W2, n_class=sp.n_class, ldl=S.CLS_PAD, logits=_r(self.logits),
                   labels=_r(self.labels), ignore_index=int(ignore_index), dlogits=_r(self.dlogits),
                   accum=_r(self.accum), grad_scale=float(grad_scale), loss=_r(self.loss),
-                  dlogits_bf16=_r(self.dlogits16), lddb=S.CLS_PAD, dbias=self.PG('classification.1.bias'))
+                  dlogits_bf16=None if self.dtype_code else _r(self.dlogits16), lddb=S.CLS_PAD,
+                  dbias=self.PG('classification.1.bias'))
         ops.op('memset', src=None, dst=_r(self.dlogits), n=self.dlogits.numel() * 4, value=0, lds=0, ldd=0, rows=0,
                cols=0, dst_cols=0, accumulate=0)
         ops.op('memset', src=None, dst=_r(self.accum), n=16, value=0, lds=0, ldd=0, rows=0, cols=0, dst_cols=0,
@@ -571,6 +574,8 @@ class Engine:
         conv = self._conv_defaults
         A = self.aslab
         H, W, M = self.H2, self.W2, self.M2
+
+        ops.dtype_code = self.dtype_code
 
         def C(**kw):
             d = dict(conv)
@@ -622,13 +627,16 @@ class Engine:
                    coefB=_r(self.coef, C_), coefC=_r(self.coef, 2 * C_), dy=_r(dy), lddy=C_, colsum=colsum)
 
         dz, dr, dy1 = self.tmp_a, self.tmp_b, self.tmp_c
+        # the low-resolution logit gradient the classifier's backward reads: the bf16 copy, or (fp32 storage) the fp32
+        # tensor itself, which ce_finalize has normalised in place
+        dlog = self.dlogits if self.dtype_code else self.dlogits16
 
         # ---- classifier
         zero(A.corr)
         mask_cls = _r(self.dropmask, 5 * sp.d1)
         WG(n_img=B, H=H, W=W, cin=sp.C_aspp, cout=S.CLS_PAD, taps=1, dil=1, x=_r(A.x), ldx=A.C, in_mask=mask_cls,
-           in_mask_ld=self.drop_ld, dz=_r(self.dlogits16), lddz=S.CLS_PAD, dw=self.PG('classification.1.weight'))
-        C(n_img=B, H=H, W=W, cin=S.CLS_PAD, cout=sp.C_aspp, taps=1, dil=1, x=_r(self.dlogits16), ldx=S.CLS_PAD,
+           in_mask_ld=self.drop_ld, dz=_r(dlog), lddz=S.CLS_PAD, dw=self.PG('classification.1.weight'))
+        C(n_img=B, H=H, W=W, cin=S.CLS_PAD, cout=sp.C_aspp, taps=1, dil=1, x=_r(dlog), ldx=S.CLS_PAD,
           w=self.WT16('classification.1.weight'), out_mask=mask_cls, out_mask_ld=self.drop_ld, g=_r(A.g), ldg=A.C,
           g_accumulate=0)
 
@@ -925,7 +933,8 @@ class Engine:
         # bf16 copy of the low-res gradient + classifier bias gradient: ce_finalize with the count pinned to 1
         ops.op('ce_finalize', n_img=self.B, h=self.H2, w=self.W2, n_class=sp.n_class, ldl=S.CLS_PAD, logits=None,
                labels=None, ignore_index=-1, dlogits=_r(self.dlogits), accum=_r(self.accum_one), grad_scale=1.0,
-               loss=None, dlogits_bf16=_r(self.dlogits16), lddb=S.CLS_PAD, dbias=self.PG('classification.1.bias'))
+               loss=None, dlogits_bf16=None if self.dtype_code else _r(self.dlogits16), lddb=S.CLS_PAD,
+               dbias=self.PG('classification.1.bias'))
         return ops
 
     # ------------------------------------------------------------------ running

