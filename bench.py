@@ -80,6 +80,7 @@ def main():
     ap.add_argument('--model', default='DenseASPP161')
     ap.add_argument('--side-wgrad', action='store_true',
                     help='dense-layer weight gradients on a second HIP stream (overlapped kernels: per-kernel times inflate)')
+    ap.add_argument('--side-wgrad3', action='store_true', help='dense-layer 3x3 weight gradients on a second stream')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
@@ -114,6 +115,7 @@ def main():
     torch.manual_seed(0)                                   # identical replicas on every rank
     model = denseASPP.DenseASPP(cfg, n_class=19, output_stride=8).to(device).train()
     model.side_wgrad = args.side_wgrad
+    model.side_wgrad3 = args.side_wgrad3
     opt = FusedAdam(model, lr=1e-4, weight_decay=1e-4)     # reference defaults: Adam, coupled L2 1e-4
     B, H, W = args.batch, args.height, args.width
     x, labels = synth_batch(B, H, W, rank, device)

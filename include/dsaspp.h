@@ -557,6 +557,8 @@ int dsaspp_program_run(dsaspp_program* p, int32_t first, int32_t last, dsaspp_st
  * later in the same run overwrites what a side op reads or reads what it writes (the engine marks the dense-layer
  * weight gradients, whose inputs live in per-layer buffers and whose outputs only the optimizer reads): two MFMA
  * kernels that are each latency bound overlap to 1.17-1.23x of their sequential time. */
+/* side = 2 marks an op that stays on the caller's stream but must not start before the side stream has finished what
+ * it was given so far (it overwrites a buffer a side op reads): the caller's stream waits for the side stream there. */
 int dsaspp_program_set_side(dsaspp_program* p, int32_t op_index, int32_t side);
 /* Per-kernel timing with HIP events on the launch stream (measurement only): ops given a
  * non-zero tag are bracketed by two events on every run until the timing is read.

@@ -71,6 +71,8 @@ class HipBackend:
             _lib.check(self.lib.dsaspp_program_add(h, code, ctypes.byref(d), ctypes.sizeof(d)))
         for i in sorted(getattr(oplist, 'side', ())):
             _lib.check(self.lib.dsaspp_program_set_side(h, i, 1))
+        for i in sorted(getattr(oplist, 'join', ())):
+            _lib.check(self.lib.dsaspp_program_set_side(h, i, 2))
         return prog
 
     def call(self, kind, stream=None, **fields):

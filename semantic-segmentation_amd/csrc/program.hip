@@ -115,7 +115,8 @@ extern "C" void dsaspp_program_destroy(dsaspp_program* p) {
 
 extern "C" int dsaspp_program_set_side(dsaspp_program* p, int32_t op_index, int32_t side) {
     DS_REQUIRE(p && op_index >= 0 && op_index < (int)p->ops.size(), "program_set_side: bad arguments");
-    p->ops[op_index].side = side ? 1 : 0;
+    DS_REQUIRE(side >= 0 && side <= 2, "program_set_side: side must be 0 (caller's stream), 1 (side stream) or 2 (join before)");
+    p->ops[op_index].side = side;
     p->any_side = false;
     for (auto& o : p->ops) p->any_side = p->any_side || o.side != 0;
     return 0;
@@ -193,7 +194,13 @@ extern "C" int dsaspp_program_run(dsaspp_program* p, int32_t first, int32_t last
         Stamp st;
         const bool timed = o.tag != 0;
         s = main_s;
-        if (o.side && p->side) {
+        if (o.side == 2 && p->side && side_used) {
+            // this op overwrites what a side op reads (or reads what it writes): the caller's stream first waits for
+            // everything the side stream has been given so far
+            if (hipEventRecord(p->join, p->side) != hipSuccess || hipStreamWaitEvent((hipStream_t)main_s, p->join, 0) != hipSuccess)
+                return dsaspp_set_error("program_run: join of the side stream failed");
+        }
+        if (o.side == 1 && p->side) {
             // the side op sees everything enqueued on the caller's stream so far
             if (hipEventRecord(p->fork, (hipStream_t)main_s) != hipSuccess || hipStreamWaitEvent(p->side, p->fork, 0) != hipSuccess)
                 return dsaspp_set_error("program_run: fork to the side stream failed");

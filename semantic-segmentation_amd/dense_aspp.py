@@ -174,6 +174,9 @@ class DenseASPP(nn.Module):
         # dense-layer weight gradients on a second HIP stream (per-layer gradient buffers, ~20 GB at batch 16):
         # +1.9 % step throughput measured, but overlapped kernels time longer individually, so it is off by default
         self.side_wgrad = False
+        # dense-layer 3x3 weight gradients next to the 3x3 data gradients on a second stream (shared buffers, joins before
+        # every overwrite): measured 275.1 / 276.7 against 276.7 / 278.4 ms per step, i.e. within run-to-run drift: off
+        self.side_wgrad3 = False
         self.max_engines = 4                     # (batch, height, width, mode) configurations kept with their buffers
         self._flat = None
         self._gflat = None

@@ -48,9 +48,13 @@ class OpList(list):
         super().__init__()
         self.dtype_code = dtype_code
         self.side = set()       # indices of ops that may run on the program's side stream (see dsaspp_program_set_side)
+        self.join = set()       # indices of ops before which the caller's stream waits for the side stream
 
     def mark_side(self):
         self.side.add(len(self) - 1)
+
+    def mark_join(self):
+        self.join.add(len(self) - 1)
 
     def op(self, kind, **fields):
         if self.dtype_code and kind in _DTYPE_OPS:
@@ -232,6 +236,9 @@ class Engine:
             # bottleneck gradients of the layers whose slab data gradients are applied together
             self.dgrad_group = max(1, min(4, int(getattr(model, 'dgrad_group', 4))))
             self.wgrad_group = bool(getattr(model, 'wgrad_group', True))
+            # the dense layers' 3x3 weight gradients on the program's side stream, next to the 3x3 data gradient of the
+            # same layer (both are latency bound and read the same two tensors)
+            self.side_wgrad3 = bool(getattr(model, 'side_wgrad3', False)) and not self.mobilenet
             self.ident_one = torch.ones(4096, dtype=f32, device=dev)
             self.ident_zero = zeros(4096)
             self.dy1_bufs = [self.tmp_c] + [zeros(max(self.M1, self.M2) * cmax_mid, bf16) for _ in range(self.dgrad_group - 1)]
@@ -603,6 +610,8 @@ class Engine:
             gradx(M=slab.M, C=cn, g=_r(slab.g, c0), ldg=slab.C, corr1=_r(slab.corr, c0), corr2=_r(slab.corr, slab.C + c0),
                   xs=_r(slab.x, c0), ldxs=slab.C, s_mean=_r(slab.mean, c0), s_rstd=_r(slab.rstd, c0), dz=_r(dz), lddz=cn,
                   **kw)
+            if self.side_wgrad3 and dz is self.tmp_a:
+                ops.mark_join()         # a 3x3 weight gradient on the side stream may still be reading this buffer
 
         def bn_bwd(name, C_, acc, count, mode, slab=None, slab_off=0, own_stats=True):
             f = dict(C=C_, acc=_r(self.acc[acc]), count=float(count), scale=self.bnt(name, 'scale', C_),
@@ -712,6 +721,8 @@ class Engine:
                     slab_extract(nxt, 0, blk.cout, dy1)
                     ops.op('avgpool_bwd', n_img=B, H=H, W=W, C=blk.cout, x=_r(dz), ldx=blk.cout, y=_r(dy1),
                            ldy=blk.cout, stat_acc=None)
+                    if self.side_wgrad3:
+                        ops.mark_join()
                 else:
                     slab_extract(nxt, 0, blk.cout, dz)
                 dz_cur = dz
@@ -752,7 +763,7 @@ class Engine:
                     WG(n_img=B, H=H, W=W, cin=l.mid, cout=l.growth, taps=9, dil=l.dil, x=_r(y1), ldx=l.mid,
                        in_scale=self.bnt(n2, 'scale', l.mid), in_shift=self.bnt(n2, 'shift', l.mid), in_relu=1, dz=_r(dz_k),
                        lddz=l.growth, dw=self.PG(l.prefix + '.conv2.weight'))
-                    if side:
+                    if side or self.side_wgrad3:
                         ops.mark_side()
                     C(n_img=B, H=H, W=W, cin=l.growth, cout=l.mid, taps=9, dil=l.dil, x=_r(dz_k), ldx=l.growth,
                       w=self.WT16(l.prefix + '.conv2.weight'), y=_r(dr), ldy=l.mid, y_f32=self.dr_f32, epi_relu=1, ref=_r(y1), ldref=l.mid,

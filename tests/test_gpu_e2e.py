@@ -80,10 +80,11 @@ def _copy_engine_state(src, dst):
         cp(getattr(src, k), getattr(dst, k))
 
 
-@pytest.mark.parametrize('output_stride,side_wgrad', [(8, False), (16, False), (8, True)])
+@pytest.mark.parametrize('output_stride,side_wgrad', [(8, False), (16, False), (8, True), (8, 3)])
 def test_train_step_tiny(output_stride, side_wgrad):
     ref, mod = make_pair(TINY_CFG, output_stride=output_stride)
-    mod.side_wgrad = side_wgrad          # dense-layer weight gradients on the program's side stream
+    mod.side_wgrad = side_wgrad is True  # dense-layer weight gradients on the program's side stream (private buffers)
+    mod.side_wgrad3 = side_wgrad == 3    # only the 3x3 ones, shared buffers with joins before every overwrite
     cpu_mod = copy.deepcopy(mod)
     cpu_mod.set_backend(kernel_model.ModelBackend())
     x, labels = make_batch(2, 64, 96)
