@@ -396,11 +396,16 @@ int dsaspp_stem3_im2col(const dsaspp_im2col_desc* d, dsaspp_stream_t stream);
  *   labels: int64 [N][8h][8w]
  *   dlogits: fp32 same shape as logits; must be zero on entry, receives the UNNORMALISED
  *            gradient (sum over pixels of softmax - onehot)
- *   accum:  fp32[2] zero on entry: {sum of per-pixel losses, number of non-ignored pixels}
- * dsaspp_ce_finalize then divides: loss[0] = accum[0]/accum[1], dlogits /= accum[1]
+ *   accum:  fp32[DSASPP_CE_ACCUM_FLOATS] zero on entry: DSASPP_CE_ACCUM_SLOTS partial {sum of per-pixel losses,
+ *            number of non-ignored pixels} pairs, pair s at accum[s*DSASPP_CE_ACCUM_STRIDE] (one per 128-byte line:
+ *            atomics on a single address are executed one after the other); their sums are the totals
+ * dsaspp_ce_finalize then divides: loss[0] = sum/count, dlogits /= count
  * (times grad_scale), writes a bf16 copy for the classifier backward and the per-class
  * column sums (the classifier bias gradient, += into dbias when non-NULL).
  */
+#define DSASPP_CE_ACCUM_SLOTS 32
+#define DSASPP_CE_ACCUM_STRIDE 32
+#define DSASPP_CE_ACCUM_FLOATS (DSASPP_CE_ACCUM_SLOTS * DSASPP_CE_ACCUM_STRIDE)
 typedef struct dsaspp_ce_desc {
     int32_t n_img, h, w;      /* low-res geometry */
     int32_t n_class; int32_t ldl;

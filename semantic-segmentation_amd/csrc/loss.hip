@@ -4,11 +4,32 @@
 // a lane owns one full-resolution column of one "cell" -- the 8x8 block of output pixels that
 // interpolates between the same four low-resolution corners -- walks its 8 rows, and keeps
 // the x-interpolated corner rows and the per-corner-row gradient sums in registers.  The 8
-// lanes of a cell are combined with DPP adds; the cells of a block meet in an LDS tile of the
-// low-resolution gradient, which leaves as contiguous fp32 atomics.  HBM traffic is the
-// low-resolution logits, the int64 labels and the low-resolution gradient.
+// lanes of a cell are combined with DPP adds; each cell leaves its four corner sums in LDS (plain
+// stores: LDS float atomics retire about one lane per 2.5 cycles), the block adds up the cells
+// that meet in each low-resolution pixel and sends the result out as contiguous fp32 atomics.
+// HBM traffic is the low-resolution logits, the int64 labels and the low-resolution gradient.
 #include "common.h"
 #include <mutex>
+
+#ifndef UPCE_WAVES
+#define UPCE_WAVES 3     // waves per SIMD the register budget allows; measured flat from 2 to 4 (the row loop is ALU work)
+#endif
+#ifndef UPCE_UNROLL
+#define UPCE_UNROLL 2
+#endif
+#ifndef UPCE_ABL
+#define UPCE_ABL 0       // diagnostic builds (timing only): 1 no per-cell LDS adds, 2 no global adds of the tile, 3 no softmax rows,
+                         // 4 no loss/count atomics
+#endif
+
+// The loss and the pixel count are summed in ACC_SLOTS (loss, count) pairs, one pair per 128-byte line, block b into
+// pair b % ACC_SLOTS: atomics on one address are executed one after the other at the memory side (about 13 ns each;
+// 139k of them from the waves of a batch of sixteen 1024x2048 images were 1.7 of this kernel's 1.8 ms).
+#ifndef UPCE_TILES_PER_BLOCK
+#define UPCE_TILES_PER_BLOCK 1
+#endif
+#define ACC_SLOTS DSASPP_CE_ACCUM_SLOTS
+#define ACC_STRIDE DSASPP_CE_ACCUM_STRIDE
 
 namespace {
 
@@ -43,150 +64,241 @@ __device__ __forceinline__ float row8_sum(float v) {
 }
 
 // EXACT: n_class == NC, no per-class range checks (they are scalar conditions: the compiler turns each into a
-// branch and the unrolled class loops into thousands of lines of duplicated code)
+// branch and the unrolled class loops into thousands of lines of duplicated code).
+//
+// The kernel is bound by vector-ALU issue in the row loop (counters: the vector ALU of every SIMD is busy for three
+// quarters of the kernel), so the row body is cut down to what the softmax itself needs, per class: one multiply-add
+// for the interpolated logit, the exponential, one add into the sum, two multiply-adds into the two corner-row
+// gradient sums.
+//  - Logits are pre-scaled by log2(e): exp and log are the bare base-2 hardware instructions.
+//  - No per-row maximum: each corner row is shifted by its own maximum once per tile (r0 - M0, r1 - M1), so the
+//    interpolated logit z - (hy*M0 + ly*M1) is never positive.  A row whose largest term still underflows (the two
+//    corner rows peak at different classes, hundreds of units apart) is redone with its true maximum.
+//  - Nothing is a select over the target class t.  The row adds its weights hy, ly to lane-private LDS sums
+//    oh0[t], oh1[t]; after the rows, g -= oh gives the -onehot(t) half of the gradient and sum_c oh[c] * r[c] the
+//    target-logit half of the loss.
+// A block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and adds its loss and pixel count once, at the end.
 template <int NC, bool EXACT>
-__global__ __launch_bounds__(256) void upce_kernel(const dsaspp_ce_desc d, const int tiles_x, const int tiles_y) {
-    constexpr int PX = UP_TCX + 1, PY = UP_TCY + 1, CS = NC + 1;     // LDS tile [PY][PX][CS]
-    __shared__ float gt[PY * PX * CS];
+__global__ __launch_bounds__(256, EXACT ? UPCE_WAVES : 1) void upce_kernel(const dsaspp_ce_desc d, const int tiles_x, const int tiles_y,
+                                                               const int n_tiles, const int vec4) {
+    constexpr int PX = UP_TCX + 1, PY = UP_TCY + 1, CS = NC + 1;
+    constexpr int NCELL = UP_TCX * UP_TCY, KS = NCELL * CS;          // ct[corner][cell][CS]
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f, NEG = -1.0e30f;
+    __shared__ float ct[4 * KS];
+    __shared__ float oh[2 * NC * 256];                               // [corner row][class][lane]: lane-private columns
+    __shared__ float part[8];
     const int h = d.h, w = d.w, H = 8 * h, W = 8 * w;
     const int cells_x = w + 1, cells_y = h + 1;
     const int tid = threadIdx.x, lane8 = tid & 7;
-    int b = blockIdx.x;
-    const int bx = b % tiles_x; b /= tiles_x;
-    const int by = b % tiles_y;
-    const int n = b / tiles_y;
-    const int ci = bx * UP_TCX + ((tid >> 3) & (UP_TCX - 1)), cj = by * UP_TCY + (tid >> 6);
-    const bool cell_ok = ci < cells_x && cj < cells_y;
-    for (int i = tid; i < PY * PX * CS; i += 256) gt[i] = 0.f;
-    const int X = 8 * ci - 4 + lane8;
-    const bool col_ok = cell_ok && X >= 0 && X < W;
-    int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
-    float lx = 0.f, ly_dummy = 0.f;
-    src_index(max(X, 0), w, x0, x1, lx);
-    // corner rows of this cell (identical for all its rows)
-    src_index(max(8 * cj - 4, 0), h, y0, y1, ly_dummy);
-    const float hx = 1.f - lx;
-    const float* L = d.logits + (int64_t)n * h * w * d.ldl;
-    float r0[NC], r1[NC], g0[NC], g1[NC];
+    const int n_class = EXACT ? NC : d.n_class;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { r0[c] = 0.f; r1[c] = 0.f; g0[c] = 0.f; g1[c] = 0.f; }
+    for (int c = 0; c < 2 * NC; ++c) oh[c * 256 + tid] = 0.f;       // each lane zeroes, reads and re-zeroes its own column
     float loss = 0.f, cnt = 0.f;
-    if (col_ok) {
-        const float* p00 = L + ((int64_t)y0 * w + x0) * d.ldl;
-        const float* p01 = L + ((int64_t)y0 * w + x1) * d.ldl;
-        const float* p10 = L + ((int64_t)y1 * w + x0) * d.ldl;
-        const float* p11 = L + ((int64_t)y1 * w + x1) * d.ldl;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int b = tile;
+        const int bx = b % tiles_x; b /= tiles_x;
+        const int by = b % tiles_y;
+        const int n = b / tiles_y;
+        const int ci = bx * UP_TCX + ((tid >> 3) & (UP_TCX - 1)), cj = by * UP_TCY + (tid >> 6);
+        const bool cell_ok = ci < cells_x && cj < cells_y;
+        const int X = 8 * ci - 4 + lane8;
+        const bool col_ok = cell_ok && X >= 0 && X < W;
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+        float lx = 0.f, ly_dummy = 0.f;
+        src_index(max(X, 0), w, x0, x1, lx);
+        // corner rows of this cell (identical for all its rows)
+        src_index(max(8 * cj - 4, 0), h, y0, y1, ly_dummy);
+        const float hx = 1.f - lx;
+        // first low-resolution pixel the tile's cells touch, before clamping (see the write-out below)
+        const int oy = by * UP_TCY - 1, ox = bx * UP_TCX - 1;
+        float r0[NC], dd[NC], g0[NC], g1[NC];      // r0 - M0;  (r1 - M1) - (r0 - M0);  gradient sums of the two corner rows
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { r0[c] = NEG; dd[c] = 0.f; g0[c] = 0.f; g1[c] = 0.f; }
+        if (col_ok) {
+            const float* L = d.logits + (int64_t)n * h * w * d.ldl;
+            const float* p00 = L + ((int64_t)y0 * w + x0) * d.ldl;
+            const float* p01 = L + ((int64_t)y0 * w + x1) * d.ldl;
+            const float* p10 = L + ((int64_t)y1 * w + x0) * d.ldl;
+            const float* p11 = L + ((int64_t)y1 * w + x1) * d.ldl;
+            const int64_t* lab = d.labels + (int64_t)n * H * W;
+            int tl[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {              // the 8 labels of this lane's column: loads in flight together
+                const int Y = 8 * cj - 4 + r;
+                tl[r] = (Y >= 0 && Y < H) ? (int)lab[(int64_t)Y * W + X] : d.ignore_index;
+            }
+            // x-interpolated corner rows in log2 units; classes past n_class stay at -1e30: their exp2() is exactly 0
+            float r1[NC];
+            if (EXACT && vec4) {
+                const float4* q00 = reinterpret_cast<const float4*>(p00);
+                const float4* q01 = reinterpret_cast<const float4*>(p01);
+                const float4* q10 = reinterpret_cast<const float4*>(p10);
+                const float4* q11 = reinterpret_cast<const float4*>(p11);
+#pragma unroll
+                for (int q = 0; q < (NC + 3) / 4; ++q) {
+                    const float4 a = q00[q], bq = q01[q], cq = q10[q], e = q11[q];
+                    const float va[4] = {a.x, a.y, a.z, a.w}, vb[4] = {bq.x, bq.y, bq.z, bq.w};
+                    const float vc[4] = {cq.x, cq.y, cq.z, cq.w}, ve[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int c = 4 * q + k;
+                        if (c < NC) {
+                            r0[c] = LOG2E * (hx * va[k] + lx * vb[k]);
+                            r1[c] = LOG2E * (hx * vc[k] + lx * ve[k]);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const bool cv = EXACT || c < d.n_class;
+                    r0[c] = cv ? LOG2E * (hx * p00[cv ? c : 0] + lx * p01[cv ? c : 0]) : NEG;
+                    r1[c] = cv ? LOG2E * (hx * p10[cv ? c : 0] + lx * p11[cv ? c : 0]) : NEG;
+                }
+            }
+            float M0 = r0[0], M1 = r1[0];
+#pragma unroll
+            for (int c = 1; c < NC; ++c) { M0 = fmaxf(M0, r0[c]); M1 = fmaxf(M1, r1[c]); }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                r0[c] -= M0;
+                dd[c] = (r1[c] - M1) - r0[c];
+            }
+            const float dM = M1 - M0;
+#pragma unroll UPCE_UNROLL
+            for (int r = 0; r < (UPCE_ABL == 3 ? 0 : 8); ++r) {
+                const int Y = 8 * cj - 4 + r;
+                const bool row_ok = Y >= 0 && Y < H;
+                int yy0, yy1;
+                float ly;
+                src_index(row_ok ? Y : 0, h, yy0, yy1, ly);
+                const float hy = 1.f - ly;
+                const int t = tl[r];
+                const float live = (t != d.ignore_index) ? 1.f : 0.f;
+                // a live label outside [0, n_class) has no class to subtract (the reference raises on it)
+                const bool tv = (t != d.ignore_index) && (unsigned)t < (unsigned)n_class;
+                float* o0 = oh + (tv ? t : 0) * 256 + tid;
+                const float s0 = o0[0], s1 = o0[NC * 256];      // read now, needed after the exponentials
+                float z[NC];
+                float se = 0.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    z[c] = __builtin_amdgcn_exp2f(fmaf(ly, dd[c], r0[c]));
+                    se += z[c];
+                }
+                const float up = fmaf(ly, dM, M0);     // what the row's logits were shifted by
+                float more_up = 0.f;
+                if (se < 1.0e-30f) {                   // even the largest term underflowed: shift by the row's true maximum
+                    float mx = -3.0e38f;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) mx = fmaxf(mx, fmaf(ly, dd[c], r0[c]));
+                    se = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        z[c] = __builtin_amdgcn_exp2f(fmaf(ly, dd[c], r0[c]) - mx);
+                        se += z[c];
+                    }
+                    more_up = mx;
+                }
+                const float inv = live / se;
+                const float a0 = hy * inv, a1 = ly * inv;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    g0[c] = fmaf(a0, z[c], g0[c]);
+                    g1[c] = fmaf(a1, z[c], g1[c]);
+                }
+                // log-sum-exp of the row, in the shifted frame for a valid target (the same shift is missing from the
+                // target-logit sum below), in the true frame otherwise
+                loss += live * (__builtin_amdgcn_logf(se) + more_up + (tv ? 0.f : up));
+                cnt += live;
+                o0[0] = s0 + (tv ? hy : 0.f);
+                o0[NC * 256] = s1 + (tv ? ly : 0.f);
+            }
+            // -onehot(t) half of the gradient and target-logit half of the loss, from the per-class weight sums
+            float zt = 0.f;
+            const bool more = tile + (int)gridDim.x < n_tiles;      // the sums start the next tile at zero
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float w0 = oh[c * 256 + tid], w1 = oh[(NC + c) * 256 + tid];
+                if (more) {
+                    oh[c * 256 + tid] = 0.f;
+                    oh[(NC + c) * 256 + tid] = 0.f;
+                }
+                g0[c] -= w0;
+                g1[c] -= w1;
+                zt = fmaf(w0, r0[c], zt);
+                zt = fmaf(w1, r0[c] + dd[c], zt);
+            }
+            loss -= zt;
+        }
+        // Combine the 8 columns of the cell: its corner (y, x0) gets the hx-weighted, (y, x1) the lx-weighted sum.
+        // Each cell stores its four corner sums in its own LDS row (plain stores, spread over its 8 lanes); cell
+        // (a, b) of the tile stands for the pixels (oy + a + {0,1}, ox + b + {0,1}) BEFORE clamping: on the image
+        // border the interpolation clamps both corners into the image, and whatever weight the outside corner would
+        // carry belongs to the nearest inside pixel (its interpolation weight there is 0, or both corners coincide).
+        const int cell = tid >> 3;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            // classes past n_class sit at -1e30: they never win the max and their exp() is exactly 0, so the row
-            // loop needs no per-class range checks
-            const bool cv = EXACT || c < d.n_class;
-            r0[c] = cv ? hx * p00[cv ? c : 0] + lx * p01[cv ? c : 0] : -1.0e30f;
-            r1[c] = cv ? hx * p10[cv ? c : 0] + lx * p11[cv ? c : 0] : -1.0e30f;
-        }
-        const int64_t* lab = d.labels + (int64_t)n * H * W;
-        int tl[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {              // the 8 labels of this lane's column: loads in flight together
-            const int Y = 8 * cj - 4 + r;
-            tl[r] = (Y >= 0 && Y < H) ? (int)lab[(int64_t)Y * W + X] : d.ignore_index;
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int Y = 8 * cj - 4 + r;
-            const bool row_ok = Y >= 0 && Y < H;
-            int yy0, yy1;
-            float ly;
-            src_index(row_ok ? Y : 0, h, yy0, yy1, ly);
-            const float hy = 1.f - ly;
-            const int t = tl[r];
-            const float live = (t != d.ignore_index) ? 1.f : 0.f;
-            // one-hot of the target as a bit mask: keeps the per-class selects plain arithmetic (a chain of
-            // (c == t) selects gets lowered to a jump table over t with one copy of the row body per class)
-            const unsigned tm = ((unsigned)t < 32u) ? (1u << t) : 0u;
-            float z[NC];
-            float mx = -3.0e38f;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                z[c] = hy * r0[c] + ly * r1[c];
-                mx = fmaxf(mx, z[c]);
+            const float a00 = row8_sum(hx * g0[c]), a01 = row8_sum(lx * g0[c]);
+            const float a10 = row8_sum(hx * g1[c]), a11 = row8_sum(lx * g1[c]);
+            if (UPCE_ABL != 1 && (c & 7) == lane8) {            // cells outside the image store their zeros
+                ct[0 * KS + cell * CS + c] = a00;
+                ct[1 * KS + cell * CS + c] = a01;
+                ct[2 * KS + cell * CS + c] = a10;
+                ct[3 * KS + cell * CS + c] = a11;
             }
-            float se = 0.f, zt = 0.f;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                zt = fmaf((float)((tm >> c) & 1u), z[c], zt);
-                const float e = __expf(z[c] - mx);
-                z[c] = e;
-                se += e;
+        }
+        __syncthreads();
+        float* G = d.dlogits + (int64_t)n * h * w * d.ldl;
+        for (int i = tid; i < PY * PX * 32; i += 256) {
+            const int c = i & 31, pix = i >> 5;
+            const int py = pix / PX, px = pix - py * PX;
+            // pixel (py, px) of the tile is corner 00 of cell (py, px), 01 of (py, px-1), 10 of (py-1, px), 11 of (py-1, px-1)
+            const int gy = min(max(oy + py, 0), h - 1), gx = min(max(ox + px, 0), w - 1);
+            if (c < NC && (EXACT || c < d.n_class)) {
+                float v = 0.f;
+                if (py < UP_TCY && px < UP_TCX) v += ct[0 * KS + (py * UP_TCX + px) * CS + c];
+                if (py < UP_TCY && px > 0) v += ct[1 * KS + (py * UP_TCX + px - 1) * CS + c];
+                if (py > 0 && px < UP_TCX) v += ct[2 * KS + ((py - 1) * UP_TCX + px) * CS + c];
+                if (py > 0 && px > 0) v += ct[3 * KS + ((py - 1) * UP_TCX + px - 1) * CS + c];
+                if (UPCE_ABL != 2 && v != 0.f) atomicAdd(G + ((int64_t)gy * w + gx) * d.ldl + c, v);
             }
-            const float inv = live / se;
-            const float lse = mx + __logf(se);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const float gcl = fmaf(z[c], inv, -live * (float)((tm >> c) & 1u));
-                g0[c] = fmaf(hy, gcl, g0[c]);
-                g1[c] = fmaf(ly, gcl, g1[c]);
-            }
-            loss += live * (lse - zt);
-            cnt += live;
         }
+        __syncthreads();                               // the corner sums are overwritten in the next round
     }
-    // combine the 8 columns of the cell: corner (y, x0) gets the hx-weighted, (y, x1) the
-    // lx-weighted sum.  Within a cell every in-range lane names the same two low-res columns
-    // (lanes left of output column 4 all clamp to (0, 1) with lx = 0), taken here from the
-    // cell's first in-range column.
-    int cx0, cx1;
-    {
-        float dummy;
-        src_index(max(8 * ci - 4, 0), w, cx0, cx1, dummy);
-    }
-    // tile-local pixel coordinates: the tile's first low-resolution pixel is (by*UP_TCY - 1, bx*UP_TCX - 1)
-    const int oy = by * UP_TCY - 1, ox = bx * UP_TCX - 1;
-    const int l00 = ((y0 - oy) * PX + (cx0 - ox)) * CS, l01 = ((y0 - oy) * PX + (cx1 - ox)) * CS;
-    const int l10 = ((y1 - oy) * PX + (cx0 - ox)) * CS, l11 = ((y1 - oy) * PX + (cx1 - ox)) * CS;
-    __syncthreads();                               // tile zeroed
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const float a00 = row8_sum(hx * g0[c]), a01 = row8_sum(lx * g0[c]);
-        const float a10 = row8_sum(hx * g1[c]), a11 = row8_sum(lx * g1[c]);
-        // the 4*n_class additions of the cell, spread over its 8 lanes
-        if (cell_ok && (EXACT || c < d.n_class) && (c & 7) == lane8) {
-            atomicAdd(gt + l00 + c, a00);
-            atomicAdd(gt + l01 + c, a01);
-            atomicAdd(gt + l10 + c, a10);
-            atomicAdd(gt + l11 + c, a11);
-        }
-    }
-    __syncthreads();
-    float* G = d.dlogits + (int64_t)n * h * w * d.ldl;
-    for (int i = tid; i < PY * PX * 32; i += 256) {
-        const int c = i & 31, pix = i >> 5;
-        const int py = pix / PX, px = pix - py * PX;
-        const int gy = oy + py, gx = ox + px;
-        if (c < NC && (EXACT || c < d.n_class) && gy >= 0 && gy < h && gx >= 0 && gx < w) {
-            const float v = gt[pix * CS + c];
-            if (v != 0.f) atomicAdd(G + ((int64_t)gy * w + gx) * d.ldl + c, v);
-        }
-    }
-    // loss / count: wave reduce, one atomic pair per wave
+    // loss / count: wave reduce, block reduce through LDS, one atomic pair per block into the block's slot
+    loss *= LN2;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         loss += __shfl_xor(loss, o, 64);
         cnt += __shfl_xor(cnt, o, 64);
     }
-    if ((threadIdx.x & 63) == 0 && cnt > 0.f) {
-        atomicAdd(d.accum, loss);
-        atomicAdd(d.accum + 1, cnt);
+    if ((tid & 63) == 0) { part[(tid >> 6) * 2] = loss; part[(tid >> 6) * 2 + 1] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+        const float ls = (part[0] + part[2]) + (part[4] + part[6]), cs = (part[1] + part[3]) + (part[5] + part[7]);
+        if (UPCE_ABL != 4 && cs > 0.f) {
+            float* slot = d.accum + (blockIdx.x % ACC_SLOTS) * ACC_STRIDE;
+            atomicAdd(slot, ls);
+            atomicAdd(slot + 1, cs);
+        }
     }
 }
 
 // dlogits /= count (x grad_scale); loss = sum/count; bf16 copy; per-class column sums -> dbias
 __global__ __launch_bounds__(256) void ce_finalize_kernel(const dsaspp_ce_desc d) {
     const int64_t M = (int64_t)d.n_img * d.h * d.w;
-    const float cnt = d.accum[1];
-    const float inv = cnt > 0.f ? d.grad_scale / cnt : 0.f;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && d.loss) d.loss[0] = cnt > 0.f ? d.accum[0] / cnt : 0.f;
     const int c = threadIdx.x & 31;
+    // lane c of each 32-lane half reads pair c; the butterfly leaves the same sums, added in the same order, in every lane
+    static_assert(ACC_SLOTS == 32, "one pair per lane of a 32-lane half");
+    float lsum = d.accum[c * ACC_STRIDE], cnt = d.accum[c * ACC_STRIDE + 1];
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        lsum += __shfl_xor(lsum, o, 64);
+        cnt += __shfl_xor(cnt, o, 64);
+    }
+    const float inv = cnt > 0.f ? d.grad_scale / cnt : 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && d.loss) d.loss[0] = cnt > 0.f ? lsum / cnt : 0.f;
     const int rsub = threadIdx.x >> 5;     // 8 rows per pass
     float colsum = 0.f;
     u16* ob = reinterpret_cast<u16*>(d.dlogits_bf16);
@@ -304,8 +416,14 @@ extern "C" int dsaspp_upsample8_ce(const dsaspp_ce_desc* d, dsaspp_stream_t stre
     const int tiles_x = (d->w + 1 + UP_TCX - 1) / UP_TCX, tiles_y = (d->h + 1 + UP_TCY - 1) / UP_TCY;
     const int64_t blocks = (int64_t)d->n_img * tiles_x * tiles_y;
     DS_REQUIRE(blocks < (1ll << 31), "upsample8_ce: grid too large");
-    if (d->n_class == 19) hipLaunchKernelGGL((upce_kernel<19, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d, tiles_x, tiles_y);
-    else hipLaunchKernelGGL((upce_kernel<32, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d, tiles_x, tiles_y);
+    // a block walks up to UPCE_TILES_PER_BLOCK tiles (fewer tile set-ups and loss atomics); small inputs keep one tile per block
+    const int64_t grid = blocks <= 2048 ? blocks : (blocks + UPCE_TILES_PER_BLOCK - 1) / UPCE_TILES_PER_BLOCK;
+    // 16-byte loads of the corner pixels: rows of 4-float groups, the last of which may reach into the row padding
+    const int vec4 = ((reinterpret_cast<uintptr_t>(d->logits) & 15) == 0 && d->ldl % 4 == 0 && d->ldl >= 20) ? 1 : 0;
+    if (d->n_class == 19)
+        hipLaunchKernelGGL((upce_kernel<19, true>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *d, tiles_x, tiles_y, (int)blocks, vec4);
+    else
+        hipLaunchKernelGGL((upce_kernel<32, false>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *d, tiles_x, tiles_y, (int)blocks, 0);
     DS_LAUNCH_CHECK("upsample8_ce");
     return 0;
 }
@@ -322,12 +440,12 @@ extern "C" int dsaspp_ce_finalize(const dsaspp_ce_desc* d, dsaspp_stream_t strea
 }
 
 // ---------------------------------------------------------------- allocation-free fused loss
-// Working memory of dsaspp_upsample8_ce_loss_noalloc: the two loss accumulators (first 64 floats) and the fp32
+// Working memory of dsaspp_upsample8_ce_loss_noalloc: the loss accumulators (first NOALLOC_HEAD floats) and the fp32
 // low-resolution gradient the cells add into.  One copy per GPU, resident from the moment the code object is loaded on
 // that GPU until the process ends; every call on a GPU uses that GPU's copy.
 #define NOALLOC_MAX_PIXELS DSASPP_NOALLOC_MAX_PIXELS   /* low-resolution pixels per call (four 1024x2048 images) */
 #define NOALLOC_LD 32                        /* floats per pixel row of the gradient staging */
-#define NOALLOC_HEAD 64                      /* floats in front of the gradient staging */
+#define NOALLOC_HEAD DSASPP_CE_ACCUM_FLOATS   /* floats in front of the gradient staging */
 static __device__ __align__(256) float scratch[NOALLOC_HEAD + (size_t)NOALLOC_MAX_PIXELS * NOALLOC_LD];
 
 constexpr int NOALLOC_MAX_DEVICES = 64;

@@ -217,7 +217,7 @@ class Engine:
 
         # ---- loss / backward temporaries
         self.labels = torch.zeros(B * height * width, dtype=torch.int64, device=dev)
-        self.accum = zeros(4)
+        self.accum = zeros(1024)      # DSASPP_CE_ACCUM_FLOATS: 32 (loss, count) pairs, one per 128-byte line
         self.loss = zeros(1)
         if training:
             self.dlogits = zeros(self.M2 * S.CLS_PAD)
@@ -565,7 +565,7 @@ class Engine:
                   dbias=self.PG('classification.1.bias'))
         ops.op('memset', src=None, dst=_r(self.dlogits), n=self.dlogits.numel() * 4, value=0, lds=0, ldd=0, rows=0,
                cols=0, dst_cols=0, accumulate=0)
-        ops.op('memset', src=None, dst=_r(self.accum), n=16, value=0, lds=0, ldd=0, rows=0, cols=0, dst_cols=0,
+        ops.op('memset', src=None, dst=_r(self.accum), n=4096, value=0, lds=0, ldd=0, rows=0, cols=0, dst_cols=0,
                accumulate=0)
         ops.op('upce', **ce)
         ops.op('ce_finalize', **ce)
@@ -935,7 +935,8 @@ class Engine:
         """dlogits (fp32 low-res, then bf16 copy) from the full-resolution NCHW fp32 gradient in self.grad_full."""
         sp = self.spec
         self.grad_full = self._zeros(self.B * sp.n_class * self.H * self.W)
-        self.accum_one = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float32, device=self.device)
+        self.accum_one = torch.zeros(1024, dtype=torch.float32, device=self.device)     # same layout as self.accum
+        self.accum_one[1] = 1.0
         ops = OpList()
         ops.op('memset', src=None, dst=_r(self.dlogits), n=self.dlogits.numel() * 4, value=0, lds=0, ldd=0, rows=0,
                cols=0, dst_cols=0, accumulate=0)

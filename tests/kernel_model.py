@@ -461,7 +461,7 @@ def op_upce(f):
     loss_sum = F.cross_entropy(full, lab, ignore_index=f['ignore_index'], reduction='sum')
     loss_sum.backward()
     cnt = (lab != f['ignore_index']).sum()
-    acc = _vec(f['accum'], 2)
+    acc = _vec(f['accum'], 1024)               # 32 partial (loss, count) pairs, stride 32 floats; the model uses the first
     acc[0] += loss_sum.detach()
     acc[1] += cnt
     dl = _view(f['dlogits'], n * h * w, ldl, ldl)
@@ -470,7 +470,7 @@ def op_upce(f):
 
 def op_ce_finalize(f):
     n, h, w, nc, ldl = f['n_img'], f['h'], f['w'], f['n_class'], f['ldl']
-    acc = _vec(f['accum'], 2)
+    acc = _vec(f['accum'], 1024).view(32, 32).sum(0)
     cnt = float(acc[1])
     inv = f['grad_scale'] / cnt if cnt > 0 else 0.0
     if f['loss'] is not None:

@@ -377,20 +377,25 @@ def test_stem_ops():
     close(out['s_acc'][0].view(R, -1).sum(0), out['s_acc'][1].view(R, -1).sum(0), 1e-3, 'maxpool_bwd.s_acc')
 
 
-@pytest.mark.parametrize('shape', [(2, 4, 6), (1, 8, 16), (3, 5, 3)])
+@pytest.mark.parametrize('shape', [(2, 4, 6), (1, 8, 16), (3, 5, 3), (1, 1, 1), (2, 1, 9), (1, 37, 21), (1, 6, 10, 'peaks')])
 def test_upsample_ce(shape):
-    n, h, w = shape
+    n, h, w = shape[:3]
     gen = torch.Generator().manual_seed(h * w)
     nc, ldl = 19, 32
     M = n * h * w
     logits = torch.randn(M * ldl, generator=gen) * 2
+    if len(shape) > 3:
+        # neighbouring pixels peak at different classes, 400 apart: between them every term of the softmax sum
+        # underflows unless the row is shifted by its own maximum
+        lv = logits.view(M, ldl)
+        lv[torch.arange(M), torch.arange(M) % nc] += 400.0
     labels = torch.randint(0, nc, (n * 64 * h * w,), generator=gen)
     labels[torch.rand(labels.shape, generator=gen) < 0.1] = 255
     f = dict(n_img=n, h=h, w=w, n_class=nc, ldl=ldl, logits=Ref(logits), labels=Ref(labels), ignore_index=255,
-             dlogits=Ref(torch.zeros(M * ldl)), accum=Ref(torch.zeros(4)), grad_scale=1.0, loss=Ref(torch.zeros(1)),
+             dlogits=Ref(torch.zeros(M * ldl)), accum=Ref(torch.zeros(1024)), grad_scale=1.0, loss=Ref(torch.zeros(1)),
              dlogits_bf16=Ref(torch.zeros(M * ldl, dtype=torch.bfloat16)), lddb=ldl, dbias=Ref(torch.zeros(32)))
     out = run_both('upce', f)
-    close(out['accum'][0][:2], out['accum'][1][:2], 1e-4, 'upce.accum')
+    close(out['accum'][0].view(32, 32).sum(0)[:2], out['accum'][1].view(32, 32).sum(0)[:2], 1e-4, 'upce.accum')
     close(out['dlogits'][0], out['dlogits'][1], 1e-4, 'upce.dlogits')
     out = run_both('ce_finalize', f)
     close(out['loss'][0], out['loss'][1], 1e-4, 'ce_finalize.loss')

@@ -39,7 +39,7 @@ def test_noalloc_loss_matches_two_call_form():
     for n, h, w, seed in ((3, 24, 40, 1), (1, 8, 16, 2)):       # the second call is smaller than the first
         f, M, ldl = _case(n, h, w, seed, dev)
         ref = _outputs(M, ldl, dev)
-        ws = dict(dlogits=Ref(torch.zeros(M * ldl, device=dev)), accum=Ref(torch.zeros(4, device=dev)))
+        ws = dict(dlogits=Ref(torch.zeros(M * ldl, device=dev)), accum=Ref(torch.zeros(1024, device=dev)))
         be.call('upce', **f, **ws, **ref)
         be.call('ce_finalize', **f, **ws, **ref)
         got = _outputs(M, ldl, dev)
