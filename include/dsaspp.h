@@ -102,6 +102,16 @@ typedef struct dsaspp_conv_desc {
     const void* x2; const void* w2; const float* es2; const float* eh2; float* sa2; int32_t sl2;
     const void* x3; const void* w3; const float* es3; const float* eh3; float* sa3; int32_t sl3;
     int32_t dtype;            /* storage type of the activation tensors: 0 = bf16 (default), 1 = fp32 (eval-mode forward only) */
+    /* Gradient read-out prologue (3x3 data gradient of a dense layer).  When gx_corr1 != NULL, x is a channel
+     * slice of a bf16 gradient slab and the operand of the convolution is what dsaspp_grad_extract computes from it,
+     *   v[m][c] = x[m][c] - gx_corr1[c] - ((gx_xs[m][c] - gx_mean[c]) * gx_rstd[c]) * gx_corr2[c]   (rounded to bf16),
+     * gx_xs being the same channel slice of the activation slab (bf16 [M][gx_ldxs]); v is also stored to
+     * gx_dz (bf16 [M][gx_lddz]) when that is non-NULL, for the weight gradient of the same layer.  Form: taps 9,
+     * dil 1, 2 or 4, (cin, cout) = (48, 192) or (32, 128), epi_relu 1 with s_acc, bf16 output y, no other prologue. */
+    const float* gx_corr1; const float* gx_corr2;
+    const void* gx_xs; int32_t gx_ldxs;
+    const float* gx_mean; const float* gx_rstd;
+    void* gx_dz; int32_t gx_lddz;
 } dsaspp_conv_desc;
 
 int dsaspp_conv_fwd(const dsaspp_conv_desc* d, dsaspp_stream_t stream);

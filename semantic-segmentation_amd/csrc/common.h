@@ -17,6 +17,9 @@ int dsaspp_dgrad_group_launch(const dsaspp_conv_desc& d, hipStream_t s);
 // halo-patch 3x3 convolution with few output channels (conv3x3_halo.hip): same return convention
 int dsaspp_conv3x3_halo_launch(const dsaspp_conv_desc& d, hipStream_t s);
 
+// 3x3 data gradient of a dense layer fused with the gradient-slab read-out (dgrad3x3_fused.hip); 0 = launched, else an error code
+int dsaspp_dgrad3x3_fused_launch(const dsaspp_conv_desc& d, hipStream_t s);
+
 // grouped 1x1 weight gradient of layers that share their input (wgrad_group.hip); 0 = launched, else an error code
 int dsaspp_wgrad_group_launch(const dsaspp_wgrad_desc& d, hipStream_t s);
 

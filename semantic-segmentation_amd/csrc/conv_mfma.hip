@@ -703,6 +703,10 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
     if (d.out_mask) DS_REQUIRE(d.out_mask_ld % 4 == 0, "conv_fwd: out_mask_ld must be a multiple of 4");
 
     DS_REQUIRE(d.dtype == 0 || d.dtype == 1, "conv_fwd: dtype must be 0 (bf16) or 1 (fp32)");
+    if (d.gx_corr1) {
+        DS_REQUIRE(d.dtype == 0, "conv_fwd: the gradient read-out prologue is a bf16 form");
+        return dsaspp_dgrad3x3_fused_launch(d, s);
+    }
     if (d.dtype == 1) return dsaspp_f32_conv(d, s);
     if (d.n_src > 1) {
         DS_REQUIRE(d.n_src <= 4, "conv_fwd: at most 4 sources (got %d)", d.n_src);

@@ -31,6 +31,14 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef DGG_NT
+#define DGG_NT 0      // 1: reference loads, slab loads and slab stores carry the non-temporal hint (streamed once: keep the weights in L2)
+#endif
+#if DGG_NT
+#define DGG_NTS " nt"
+#else
+#define DGG_NTS ""
+#endif
 #ifndef DGG_ABL
 #define DGG_ABL 0     // diagnostic builds (timing only, results wrong): 1 no fragment reads / MFMA, 2 no per-source mask / sums, 3 no operand DMA,
                       // 4 no side loads and no slab stores, 6 no per-step barrier
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
                 int q = qb + wq * TQ + ec * 4;
                 q = q < cout - 4 ? q : cout - 4;
                 const uint32_t off = ((uint32_t)p * (uint32_t)a.ldref + q) * 2u;
-                asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(rfp[j][rp]) : "v"(off), "s"(base) : "memory");
+                asm volatile("global_load_dwordx2 %0, %1, %2" DGG_NTS : "=v"(rfp[j][rp]) : "v"(off), "s"(base) : "memory");
             }
     };
     gvec_t gold[MP][NRP];
@@ -263,8 +271,8 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
 #pragma unroll
             for (int rp = 0; rp < NRP; ++rp) {
                 const uint32_t off = slab_off(pb, qb, j, rp);
-                if (GBF16) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(gold[j][rp]) : "v"(off), "s"(base) : "memory");
-                else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(gold[j][rp]) : "v"(off), "s"(base) : "memory");
+                if (GBF16) asm volatile("global_load_dwordx2 %0, %1, %2" DGG_NTS : "=v"(gold[j][rp]) : "v"(off), "s"(base) : "memory");
+                else asm volatile("global_load_dwordx4 %0, %1, %2" DGG_NTS : "=v"(gold[j][rp]) : "v"(off), "s"(base) : "memory");
             }
     };
 
@@ -597,13 +605,13 @@ __global__ __launch_bounds__(NT, 2) void dgrad_group_kernel(const GArgs a) {
                     o.x = pack_bf2(t[0], t[1]);
                     o.y = pack_bf2(t[2], t[3]);
                     if (full) {
-                        asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(off), "v"(o), "s"(gbase) : "memory");
+                        asm volatile("global_store_dwordx2 %0, %1, %2" DGG_NTS : : "v"(off), "v"(o), "s"(gbase) : "memory");
                     } else if (p_base + wp * TP + j * 16 + rp * RPP + er < M && q_base + wq * TQ + ec * 4 < cout) {
                         *reinterpret_cast<u32x2*>(gbase + off) = o;
                     }
                 } else {
                     if (full) {
-                        asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(off), "v"(t), "s"(gbase) : "memory");
+                        asm volatile("global_store_dwordx4 %0, %1, %2" DGG_NTS : : "v"(off), "v"(t), "s"(gbase) : "memory");
                     } else if (p_base + wp * TP + j * 16 + rp * RPP + er < M && q_base + wq * TQ + ec * 4 < cout) {
                         *reinterpret_cast<f32x4*>(gbase + off) = t;
                     }

@@ -177,6 +177,7 @@ class DenseASPP(nn.Module):
         # dense-layer 3x3 weight gradients next to the 3x3 data gradients on a second stream (shared buffers, joins before
         # every overwrite): measured 275.1 / 276.7 against 276.7 / 278.4 ms per step, i.e. within run-to-run drift: off
         self.side_wgrad3 = False
+        self.fuse_extract3 = True                # read a dense layer's gradient out of the slab inside its 3x3 data gradient
         self.max_engines = 4                     # (batch, height, width, mode) configurations kept with their buffers
         self._flat = None
         self._gflat = None

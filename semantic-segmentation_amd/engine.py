@@ -236,6 +236,7 @@ class Engine:
             # bottleneck gradients of the layers whose slab data gradients are applied together
             self.dgrad_group = max(1, min(4, int(getattr(model, 'dgrad_group', 4))))
             self.wgrad_group = bool(getattr(model, 'wgrad_group', True))
+            self.fuse_extract3 = bool(getattr(model, 'fuse_extract3', True))
             # the dense layers' 3x3 weight gradients on the program's side stream, next to the 3x3 data gradient of the
             # same layer (both are latency bound and read the same two tensors)
             self.side_wgrad3 = bool(getattr(model, 'side_wgrad3', False)) and not self.mobilenet
@@ -759,17 +760,31 @@ class Engine:
                     dy1k = self.dy1_l[l.prefix] if side else self.dy1_bufs[k]
                     dz_k = self.dz_l[l.prefix] if side else self.tmp_a
                     grp_dy1.append(dy1k)
-                    slab_extract(slab, l.cin, l.growth, dz_k)
+                    # The read-out of the layer's gradient from the slab is the prologue of its 3x3 data gradient where the
+                    # library has that form (bf16 slab and activations, the dense-layer shapes and dilations): the halo
+                    # patch is read from the two slab slices directly and its own pixels leave as dz for the weight gradient.
+                    fused = (self.fuse_extract3 and not self.dtype_code and self.g_bf16 and not self.dr_f32 and l.dil in (1, 2, 4)
+                             and (l.growth, l.mid) in ((48, 192), (32, 128)))
+                    conv3 = dict(n_img=B, H=H, W=W, cin=l.growth, cout=l.mid, taps=9, dil=l.dil,
+                                 w=self.WT16(l.prefix + '.conv2.weight'), y=_r(dr), ldy=l.mid, y_f32=self.dr_f32, epi_relu=1, ref=_r(y1),
+                                 ldref=l.mid, e_scale=self.bnt(n2, 'scale', l.mid), e_shift=self.bnt(n2, 'shift', l.mid),
+                                 e_mean=self.bnt(n2, 'mean', l.mid), e_rstd=self.bnt(n2, 'rstd', l.mid),
+                                 s_acc=_r(self.acc[l.prefix + '.s2']))
+                    if fused:
+                        C(x=_r(slab.g, l.cin), ldx=slab.C, gx_corr1=_r(slab.corr, l.cin), gx_corr2=_r(slab.corr, slab.C + l.cin),
+                          gx_xs=_r(slab.x, l.cin), gx_ldxs=slab.C, gx_mean=_r(slab.mean, l.cin), gx_rstd=_r(slab.rstd, l.cin),
+                          gx_dz=_r(dz_k), gx_lddz=l.growth, **conv3)
+                        if self.side_wgrad3 and dz_k is self.tmp_a:
+                            ops.mark_join()
+                    else:
+                        slab_extract(slab, l.cin, l.growth, dz_k)
                     WG(n_img=B, H=H, W=W, cin=l.mid, cout=l.growth, taps=9, dil=l.dil, x=_r(y1), ldx=l.mid,
                        in_scale=self.bnt(n2, 'scale', l.mid), in_shift=self.bnt(n2, 'shift', l.mid), in_relu=1, dz=_r(dz_k),
                        lddz=l.growth, dw=self.PG(l.prefix + '.conv2.weight'))
                     if side or self.side_wgrad3:
                         ops.mark_side()
-                    C(n_img=B, H=H, W=W, cin=l.growth, cout=l.mid, taps=9, dil=l.dil, x=_r(dz_k), ldx=l.growth,
-                      w=self.WT16(l.prefix + '.conv2.weight'), y=_r(dr), ldy=l.mid, y_f32=self.dr_f32, epi_relu=1, ref=_r(y1), ldref=l.mid,
-                      e_scale=self.bnt(n2, 'scale', l.mid), e_shift=self.bnt(n2, 'shift', l.mid),
-                      e_mean=self.bnt(n2, 'mean', l.mid), e_rstd=self.bnt(n2, 'rstd', l.mid),
-                      s_acc=_r(self.acc[l.prefix + '.s2']))
+                    if not fused:
+                        C(x=_r(dz_k), ldx=l.growth, **conv3)
                     bn_bwd(n2, l.mid, l.prefix + '.s2', M, 0)
                     bn_apply(l.mid, M, dr, y1, dy1k)
                     if not group_wgrad:

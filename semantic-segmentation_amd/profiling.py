@@ -13,12 +13,14 @@ CLASSES = ['untimed',
            'conv_kernel<128,64,2,2>', 'conv_kernel<128,32,4,1>',
            'wgrad_kernel<64,192,1,4>', 'wgrad_kernel<192,128,4,2>', 'wgrad_kernel<128,128,2,4>',
            'upce_kernel<19>', 'wgrad_kernel<48,192,1,4>', 'wgrad_kernel<32,192,1,4>', 'dgrad_group_kernel', 'conv3x3_halo_kernel',
-           'conv1x1_stream_kernel<192>', 'conv1x1_stream_kernel<128>', 'wgrad_group_kernel']
+           'conv1x1_stream_kernel<192>', 'conv1x1_stream_kernel<128>', 'wgrad_group_kernel', 'dgrad3x3_fused_kernel']
 
 
 def kernel_class(kind, f):
     if kind == 'conv':
         co = f['cout']
+        if f.get('gx_corr1') is not None:
+            return 17
         if (f.get('n_src') or 0) > 1 or (
                 f.get('g') is not None and co >= int(os.environ.get('DSASPP_DGG_MIN_COUT', 48)) and f['taps'] == 1 and f.get('epi_relu') and f.get('ref') is not None
                 and f.get('e_scale') is not None and f.get('e_mean') is not None and f.get('in_scale') is None
@@ -78,6 +80,8 @@ def work(kind, f):
         by = esz * M * f['cin'] * n + esz * f['cout'] * f['taps'] * f['cin'] * n
         if f.get('ref') is not None:
             by += 2.0 * M * f['cout']
+        if f.get('gx_corr1') is not None:      # the activation slice of the read-out, the read-out copy written
+            by += 2.0 * M * f['cin'] * (2 if f.get('gx_dz') is not None else 1)
         if f.get('g') is not None:
             gsz = 2.0 if f.get('g_bf16') else 4.0
             by += gsz * M * f['cout'] * (2 if f.get('g_accumulate') else 1)

@@ -57,6 +57,13 @@ def op_conv(f):
     n, H, W, cin, cout, taps, dil = f['n_img'], f['H'], f['W'], f['cin'], f['cout'], f['taps'], f['dil']
     M, hw = n * H * W, H * W
     x = _view(f['x'], M, cin, f['ldx']).to(torch.float32)
+    if f.get('gx_corr1') is not None:
+        # gradient read-out prologue: what grad_extract computes from the slab slice, rounded to bf16; optional copy out
+        xs = _view(f['gx_xs'], M, cin, f['gx_ldxs']).to(torch.float32)
+        x = x - (_vec(f['gx_corr1'], cin) + ((xs - _vec(f['gx_mean'], cin)) * _vec(f['gx_rstd'], cin)) * _vec(f['gx_corr2'], cin))
+        x = _rbf(x)
+        if f.get('gx_dz') is not None:
+            _view(f['gx_dz'], M, cin, f['gx_lddz']).copy_(x.to(bf16))
     a = _prologue(x, f, n, hw, cin)
     w = _view(f['w'], cout, taps * cin, taps * cin).to(torch.float32)
     if taps == 1:

@@ -377,6 +377,39 @@ def test_stem_ops():
     close(out['s_acc'][0].view(R, -1).sum(0), out['s_acc'][1].view(R, -1).sum(0), 1e-3, 'maxpool_bwd.s_acc')
 
 
+DGRAD3_FUSED_CASES = [
+    # n, H, W, cin, cout, dil: image sizes that are not multiples of the 8 x 32 patch, every built dilation
+    (2, 13, 45, 48, 192, 2),
+    (1, 20, 70, 48, 192, 4),
+    (1, 9, 33, 48, 192, 1),
+    (2, 11, 40, 32, 128, 2),
+    (1, 8, 32, 32, 128, 4),
+    (1, 17, 64, 32, 128, 1),
+    (1, 3, 5, 48, 192, 4),       # smaller than the dilation halo in both directions
+]
+
+
+@pytest.mark.parametrize('case', range(len(DGRAD3_FUSED_CASES)))
+def test_dgrad3x3_with_gradient_readout(case):
+    """3x3 data gradient of a dense layer with the slab read-out as its prologue: masked output, the read-out copy
+    (the weight gradient's operand) and the BatchNorm-backward sums against the kernel model."""
+    n, H, W, cin, cout, dil = DGRAD3_FUSED_CASES[case]
+    gen = torch.Generator().manual_seed(70 + case)
+    M, LD, c0 = n * H * W, cin + 200, 104
+    f = conv_fields(n, H, W, cin, cout, 9, dil, ldx=LD, scale=False, relu=False, epi_relu=True, e_scale=True, s_acc=True,
+                    xoff=c0, seed=70 + case)
+    f['x'] = Ref(bf(torch.randn(M * LD + c0, generator=gen)), c0)                  # gradient slab, channel slice at c0
+    f.update(gx_corr1=Ref(torch.randn(LD, generator=gen) * 0.1, c0), gx_corr2=Ref(torch.randn(LD, generator=gen) * 0.1, c0),
+             gx_xs=Ref(bf(torch.randn(M * LD + c0, generator=gen)), c0), gx_ldxs=LD,
+             gx_mean=Ref(torch.randn(LD, generator=gen) * 0.2, c0), gx_rstd=Ref(torch.rand(LD, generator=gen) + 0.5, c0),
+             gx_dz=Ref(torch.zeros(M * cin, dtype=torch.bfloat16)), gx_lddz=cin)
+    out = run_both('conv', f)
+    # the read-out is the same arithmetic on both sides: at most a bf16 rounding step apart where an fma was contracted
+    close(out['gx_dz'][0], out['gx_dz'][1], 8e-3, 'gx_dz')
+    close(out['y'][0], out['y'][1], 2e-2, 'dr')
+    close(out['s_acc'][0].view(R, -1).sum(0), out['s_acc'][1].view(R, -1).sum(0), 2e-2, 's_acc')
+
+
 @pytest.mark.parametrize('shape', [(2, 4, 6), (1, 8, 16), (3, 5, 3), (1, 1, 1), (2, 1, 9), (1, 37, 21), (1, 6, 10, 'peaks')])
 def test_upsample_ce(shape):
     n, h, w = shape[:3]

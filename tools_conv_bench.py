@@ -22,6 +22,7 @@ y512 = torch.randn(M*512, device=dev).to(bf); w512 = (torch.randn(2112*512, devi
 y1b, y1c, y1d = (torch.randn(M*192, device=dev).to(bf) for _ in range(3))
 acc1, acc2, acc3 = (torch.zeros(R*2*LD, device=dev) for _ in range(3))
 dr = torch.zeros(M*192, device=dev)
+dr16 = torch.zeros(M*192, device=dev).to(bf)
 def vec(c, lo=0.5): return torch.rand(c, device=dev) + lo
 w1 = (torch.randn(192*CIN, device=dev)*0.03).to(bf); w1t = (torch.randn(192*CIN, device=dev)*0.03).to(bf)
 w2 = (torch.randn(48*9*192, device=dev)*0.03).to(bf); w2t = (torch.randn(48*9*192, device=dev)*0.03).to(bf)
@@ -58,6 +59,17 @@ cases = {
  'wgrad1x1': ('wgrad', dict(n_img=n, H=H, W=W, cin=CIN, cout=192, taps=1, dil=1, x=Ref(slab), ldx=LD, in_scale=Ref(sc1), in_shift=Ref(sh1), in_relu=1, in_mask=None, in_mask_ld=0, dz=Ref(y1), lddz=192, dw=Ref(dw1), ksplit=0)),
  'wgrad3x3': ('wgrad', dict(n_img=n, H=H, W=W, cin=192, cout=48, taps=9, dil=2, x=Ref(y1), ldx=192, in_scale=Ref(sc2), in_shift=Ref(sh2), in_relu=1, in_mask=None, in_mask_ld=0, dz=Ref(dz48), lddz=48, dw=Ref(dw2), ksplit=0)),
 }
+for cn in (48, 96, 144):      # in-group data gradient: a narrow column range at channel CIN - cn of the slab
+    c_lo = CIN - cn
+    cases['narrow%d' % cn] = conv(n_img=n, H=H, W=W, cin=192, cout=cn, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t, c_lo * 192), epi_relu=1, ref=Ref(slab, c_lo), ldref=LD,
+                                  e_scale=Ref(sc1, c_lo), e_shift=Ref(sh1, c_lo), e_mean=Ref(mean, c_lo), e_rstd=Ref(rstd, c_lo), s_acc=Ref(acc, c_lo), s_ld=CIN, g=Ref(g16, c_lo), ldg=LD,
+                                  g_accumulate=1, g_bf16=1)
+corr = torch.randn(2*LD, device=dev) * 0.1
+for dl in (1, 2, 4):          # 3x3 data gradient with the slab read-out as its prologue
+    c_lo = CIN - 48
+    cases['dgrad3x3_fused_d%d' % dl] = conv(n_img=n, H=H, W=W, cin=48, cout=192, taps=9, dil=dl, x=Ref(g16, c_lo), ldx=LD, w=Ref(w2t), y=Ref(dr16), ldy=192, epi_relu=1, ref=Ref(y1), ldref=192,
+        e_scale=Ref(sc2), e_shift=Ref(sh2), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc), gx_corr1=Ref(corr, c_lo), gx_corr2=Ref(corr, LD + c_lo), gx_xs=Ref(slab, c_lo), gx_ldxs=LD,
+        gx_mean=Ref(mean, c_lo), gx_rstd=Ref(rstd, c_lo), gx_dz=Ref(dz48), gx_lddz=48)
 dwg = [torch.zeros(192*CIN, device=dev) for _ in range(4)]
 def wgroup(nsrc, ks=0):
     f = dict(n_img=n, H=H, W=W, cin=CIN, cout=192, taps=1, dil=1, x=Ref(slab), ldx=LD, in_scale=Ref(sc1), in_shift=Ref(sh1), in_relu=1, in_mask=None,
