@@ -114,25 +114,31 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const dsaspp_conv_d
         __syncthreads();
         if (c0 + 64 < cin) load_raw(c0 + 64);           // next chunk: in flight during the nine taps
 
-        // ---- nine taps out of LDS
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        // ---- nine taps out of LDS.  The fragments of a (tap, K half) group are read one group ahead of the MFMAs
+        //      that use them (explicit double buffer, order pinned with scheduling barriers): left to itself the
+        //      compiler reads each group right before its MFMAs and the wave waits out an LDS round trip per group.
+        bf16x8 afb[2][MP], wfb[2][MQ];
+        auto read_group = [&](const int t) {
+            const int tap = t >> 1, ks = t & 1;
             const int tyy = tap / 3, txx = tap - tyy * 3;
             const int toff = ((tyy - 1) * DIL * HW2 + (txx - 1) * DIL) * ROWB;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 af[MP], wf[MQ];
+            for (int j = 0; j < MP; ++j) afb[t & 1][j] = *reinterpret_cast<const bf16x8*>(smem + rbase[j] + toff + ks * 64);
 #pragma unroll
-                for (int j = 0; j < MP; ++j) af[j] = *reinterpret_cast<const bf16x8*>(smem + rbase[j] + toff + ks * 64);
+            for (int i = 0; i < MQ; ++i)
+                wfb[t & 1][i] = *reinterpret_cast<const bf16x8*>(wlds + (tap * MQ + i) * 2048 + (ks ? woff1 : woff0));
+        };
+        read_group(0);
 #pragma unroll
-                for (int i = 0; i < MQ; ++i)
-                    wf[i] = *reinterpret_cast<const bf16x8*>(wlds + (tap * MQ + i) * 2048 + (ks ? woff1 : woff0));
+        for (int t = 0; t < 18; ++t) {
+            if (t + 1 < 18) read_group(t + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < MQ; ++i)
+            for (int i = 0; i < MQ; ++i)
 #pragma unroll
-                    for (int j = 0; j < MP; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-            }
+                for (int j = 0; j < MP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfb[t & 1][i], afb[t & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
