@@ -252,3 +252,30 @@ def test_fused_adam_after_autograd_backward():
     torch.cuda.synchronize()
     for (n, p), (_, q) in zip(mod.named_parameters(), twin.named_parameters()):
         assert torch.allclose(p, q, atol=2e-6, rtol=1e-4), n
+
+
+def test_fused_and_separate_gradient_readout_agree():
+    """DenseASPP121 (growth 32, bottleneck 128: a shape the fused 3x3 data gradient is built for) at 64x128: one training
+    step with the gradient read-out inside the 3x3 data gradient and one with grad_extract + the generic kernel, same
+    weights, inputs and dropout masks.  Both round the read-out to bf16 at the same point; only the kernels'
+    summation orders differ."""
+    from cfgs import DenseASPP121
+    ref, mod = make_pair(DenseASPP121.Model_CFG, randomize_bn=False)
+    x, labels = make_batch(1, 64, 128)
+    masks = {k: v.cuda() for k, v in make_dropout_masks(ref, 1, torch.Generator().manual_seed(5)).items()}
+    mod = mod.cuda().train()
+    grads, losses = [], []
+    for fused in (True, False):
+        mod.load_state_dict(ref.state_dict())          # a training step moves the running statistics
+        mod.fuse_extract3 = fused
+        mod._engines.clear()                           # the flag is read when an engine is built
+        losses.append(float(mod.train_step(x.cuda(), labels.cuda(), dropout_masks=masks)))
+        torch.cuda.synchronize()
+        eng = mod.engine(1, 64, 128, True)
+        kinds = [k for k, f in eng._bwd.keepalive if k == 'conv' and f.get('gx_corr1') is not None]
+        assert (len(kinds) > 0) == fused, (fused, len(kinds))
+        grads.append({n: p.grad.detach().cpu().clone() for n, p in mod.named_parameters()})
+    assert losses[0] == losses[1]
+    rel, cos, worst = grad_report(grads[1], grads[0])
+    print('fused vs separate read-out: rel-L2 %.2e, cos %.7f (%s)' % (rel, cos, worst))
+    assert rel < 1e-2 and cos > 0.9999, (rel, cos, worst)

@@ -1,0 +1,125 @@
+// Measurement tool (not part of the library): how fast can a CU fill LDS by DMA (global_load_lds_dwordx4) in the
+// shape the DMA-fed GEMM kernels use -- 8 waves, a ring of 32 KiB stages, 4 DMA instructions per wave and stage,
+// one counted wait and one barrier per step -- from an L2-resident window or from an HBM stream, alone and beside
+// the LDS fragment reads and MFMAs of a K-step.
+//   hipcc --offload-arch=gfx950 -O3 -o dma_fill_bench tools/dma_fill_bench.hip && ./dma_fill_bench
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int STAGE = 32 * 1024;
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+
+// DEPTH stages in flight, ring of DEPTH + 1 slots.  row_stride: bytes between the 256 rows of a stage (128 = the stage
+// is one contiguous 32 KiB block); a stage advances step_stride bytes per step for `ksteps` steps, then the next 256
+// rows follow.  window: the source wraps at this many bytes (small: L2 resident; 0: no wrap, HBM stream).
+template <int DEPTH, bool BAR, int NRD, int NMF>
+__global__ __launch_bounds__(512, 2) void fill(const unsigned char* __restrict__ src, const size_t window, const size_t block_span,
+                                               const int row_stride, const int step_stride, const int ksteps, const int steps, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t ring_l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)smem);
+    const size_t base = (size_t)blockIdx.x * block_span;
+    int c_step = 0, c_slot = 0;
+    auto issue = [&]() {
+        const int tile = c_step / ksteps, kk = c_step - tile * ksteps;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (i * 8 + wave) * 8 + (lane >> 3);
+            size_t off = base + ((size_t)tile * 256 + row) * row_stride + (size_t)kk * step_stride + (lane & 7) * 16;
+            if (window) off %= window;
+            const unsigned char* p = src + off;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                         : : "s"(ring_l + c_slot * STAGE + (i * 8 + wave) * 1024), "v"(p) : "memory");
+        }
+        ++c_step;
+        c_slot = c_slot == DEPTH ? 0 : c_slot + 1;
+    };
+    for (int i = 0; i < DEPTH; ++i) issue();
+    f32x4 acc[4] = {};
+    int r_slot = 0;
+    for (int s = 0; s < steps; ++s) {
+        wait_vm<4 * (DEPTH - 1)>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (BAR) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue();
+        const unsigned char* st = smem + r_slot * STAGE;
+        bf16x8 fr[NRD > 0 ? NRD : 1];
+#pragma unroll
+        for (int r = 0; r < NRD; ++r) fr[r] = *reinterpret_cast<const bf16x8*>(st + ((r * 16 + (lane & 15)) * 128 + (((lane >> 4) ^ ((lane >> 1) & 7)) << 4)) % STAGE);
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) acc[m & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[NRD > 0 ? m % NRD : 0], fr[NRD > 0 ? (m + 1) % NRD : 0], acc[m & 3], 0, 0, 0);
+        if (NMF == 0 && NRD > 0) {
+#pragma unroll
+            for (int r = 0; r < NRD; ++r) acc[r & 3][0] += __builtin_bit_cast(f32x4, fr[r])[0];
+        }
+        r_slot = r_slot == DEPTH ? 0 : r_slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // nothing of this block may land in LDS after it has gone
+    const float t = acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0];
+    if (t == 12345.678f) out[blockIdx.x * 512 + tid] = t;
+}
+
+template <int DEPTH, bool BAR, int NRD, int NMF>
+void run(const char* name, const unsigned char* src, size_t window, size_t block_span, int row_stride, int step_stride, int ksteps, int steps, float* out, int blocks) {
+    auto kern = fill<DEPTH, BAR, NRD, NMF>;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const size_t lds = (size_t)(DEPTH + 1) * STAGE;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, src, window, block_span, row_stride, step_stride, ksteps, steps, out);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, src, window, block_span, row_stride, step_stride, ksteps, steps, out);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / 3, bytes = (double)blocks * steps * STAGE;
+    printf("%-46s depth %d bar %d reads %2d mfma %2d: %8.1f us  %6.2f TB/s  %5.1f B/clk/CU (2.4 GHz, %d CUs)\n", name, DEPTH, (int)BAR, NRD, NMF, us,
+           bytes / us / 1e6, bytes / blocks / (us * 1e-6 * 2.4e9), blocks);
+}
+
+int main() {
+    const int blocks = 256, steps = 2048;
+    const size_t big = (size_t)6 << 30;
+    unsigned char* src;
+    float* out;
+    CHECK(hipMalloc(&src, big));
+    CHECK(hipMemset(src, 0x3c, big));
+    CHECK(hipMalloc(&out, (size_t)blocks * 512 * 4));
+    const size_t span_c = (size_t)steps * STAGE;                       // contiguous stream: each block its own 64 MiB
+    // ---- L2-resident window (2 MiB shared by all blocks), contiguous stages
+#define L2C(D, B, R, M) run<D, B, R, M>("L2 window 2 MiB, contiguous stages", src, (size_t)2 << 20, (size_t)STAGE * 3, 128, STAGE, 1 << 30, steps, out, blocks)
+    L2C(3, true, 0, 0);
+    L2C(3, false, 0, 0);
+    L2C(2, true, 0, 0);
+    L2C(3, true, 12, 0);
+    L2C(3, true, 12, 16);
+    L2C(3, false, 12, 16);
+    // ---- L2-resident, rows of a 4224-byte pitch (a slab), 16 K-steps per 256-row tile
+#define L2S(D, B, R, M) run<D, B, R, M>("L2 window 2 MiB, 4224-byte row pitch", src, (size_t)2 << 20, (size_t)256 * 4224, 4224, 128, 16, steps, out, blocks)
+    L2S(3, true, 0, 0);
+    L2S(3, true, 12, 16);
+    // ---- HBM stream, contiguous
+#define HBC(D, B, R, M) run<D, B, R, M>("HBM stream, contiguous stages", src, big, span_c / 4, 128, STAGE, 1 << 30, steps / 4, out, blocks)
+    HBC(3, true, 0, 0);
+    HBC(3, true, 12, 16);
+    // ---- HBM stream, slab rows: every block walks its own tiles
+#define HBS(D, B, R, M) run<D, B, R, M>("HBM stream, 4224-byte row pitch", src, big, (size_t)(steps / 4 / 16) * 256 * 4224, 4224, 128, 16, steps / 4, out, blocks)
+    HBS(3, true, 0, 0);
+    HBS(3, true, 12, 16);
+    return 0;
+}
