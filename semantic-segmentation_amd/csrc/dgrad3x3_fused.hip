@@ -18,6 +18,19 @@
 #define D3F_ABL 0     // diagnostic builds (timing only, results wrong): 1 no slab loads for the patch, 2 no MFMA, 3 no epilogue loads / stores
 #endif
 
+#ifndef D3F_STAMP
+#define D3F_STAMP 0   // diagnostic build: wave 0 of every block records the shader clock at its phase boundaries (tools_d3f_stamps.py)
+#endif
+#if D3F_STAMP
+__device__ unsigned long long d3f_stamps[4096 * 16];
+extern "C" int dsaspp_debug_read_stamps(void* host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(d3f_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+#define STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) d3f_stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int TH = 8, TW = 32, NT = 512;
@@ -98,8 +111,10 @@ __global__ __launch_bounds__(NT, 2) void dgrad3x3_fused_kernel(const dsaspp_conv
             if (idx < COUT * G::WCPR) *reinterpret_cast<u32x4*>(wlds + row * G::WROWB + c * 16) = wv[u];
         }
     };
+    STAMP(0);
     load_w(0);
     __syncthreads();                                    // read-out tables visible
+    STAMP(1);
 
     // ---- the halo patch: read-out applied on the way into LDS, zero padding after it; own pixels also go to gx_dz.
     //      Every load of the patch is issued before the first one is used.  A thread keeps one 8-channel chunk
@@ -123,11 +138,20 @@ __global__ __launch_bounds__(NT, 2) void dgrad3x3_fused_kernel(const dsaspp_conv
             gv[u] = *reinterpret_cast<const u32x4*>(gs + p * d.ldx + (ok ? ck * 8 : 0));
             xv[u] = *reinterpret_cast<const u32x4*>(xs + p * d.gx_ldxs + (ok ? ck * 8 : 0));
         }
-        float k1[8], k2[8], sm[8], sr[8];
-        load8f(gtab + ck * 8, k1);
-        load8f(gtab + CIN + ck * 8, k2);
-        load8f(gtab + 2 * CIN + ck * 8, sm);
-        load8f(gtab + 3 * CIN + ck * 8, sr);
+        // v = g - corr1 - ((x - mean) * rstd) * corr2 = g + x * al + be, with al = -rstd * corr2, be = mean * rstd * corr2 - corr1
+        float al[8], be[8];
+        {
+            float k1[8], k2[8], sm[8], sr[8];
+            load8f(gtab + ck * 8, k1);
+            load8f(gtab + CIN + ck * 8, k2);
+            load8f(gtab + 2 * CIN + ck * 8, sm);
+            load8f(gtab + 3 * CIN + ck * 8, sr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                al[e] = -sr[e] * k2[e];
+                be[e] = fmaf(-sm[e], al[e], -k1[e]);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int pix = pix0 + u * PPP;
@@ -139,7 +163,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad3x3_fused_kernel(const dsaspp_conv
             unpack8(uint4{gv[u].x, gv[u].y, gv[u].z, gv[u].w}, v);
             unpack8(uint4{xv[u].x, xv[u].y, xv[u].z, xv[u].w}, x);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] -= k1[e] + ((x[e] - sm[e]) * sr[e]) * k2[e];
+            for (int e = 0; e < 8; ++e) v[e] += fmaf(x[e], al[e], be[e]);
             uint4 o = pack8(v);
             o.x = ok ? o.x : 0u; o.y = ok ? o.y : 0u; o.z = ok ? o.z : 0u; o.w = ok ? o.w : 0u;
             const bool own = ok && hy >= DIL && hy < DIL + TH && hx >= DIL && hx < DIL + TW;
@@ -148,6 +172,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad3x3_fused_kernel(const dsaspp_conv
         }
     }
 
+    STAMP(2);                                           // patch staged (this wave's share)
     // ---- fragment coordinates: lane (fr, g) = row fr of a 16-row tile, K chunk g of a 32-wide step
     const int fr = lane & 15, g = lane >> 4;
     f32x4 acc[MQ][MP];
@@ -180,8 +205,10 @@ __global__ __launch_bounds__(NT, 2) void dgrad3x3_fused_kernel(const dsaspp_conv
 #pragma unroll
     for (int ph = 0; ph < 3; ++ph) {
         if (ph) __syncthreads();                        // every wave has left the previous phase's filter rows
+        STAMP(3 + 3 * ph);
         store_w();
         __syncthreads();                                // filter rows (and, the first time, the patch) visible
+        STAMP(4 + 3 * ph);
         if (ph < 2) load_w(ph + 1);                     // in flight during this phase's MFMAs
         if (ph == 2) {
 #pragma unroll
@@ -225,6 +252,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad3x3_fused_kernel(const dsaspp_conv
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
+        STAMP(5 + 3 * ph);
     }
 
     // ---- epilogue: lane holds output channels q = i*16 + g*4 .. +3 of pixels (ty0 + wave, tx0 + j*16 + fr)
@@ -233,24 +261,42 @@ __global__ __launch_bounds__(NT, 2) void dgrad3x3_fused_kernel(const dsaspp_conv
     for (int i = MQ / 2; i < MQ; ++i)
 #pragma unroll
         for (int j = 0; j < MP; ++j) rr[i][j] = D3F_ABL == 3 ? make_uint2(0x3f803f80u, 0x3f803f80u) : *reinterpret_cast<const uint2*>(rg + poff[j] * d.ldref + i * 16 + g * 4);
-    __syncthreads();                                    // patch and filter rows are dead: the patch becomes the table of sums
+    // patch and filter rows are dead: the patch becomes the table of sums.  The barrier waits for this wave's LDS
+    // operations only; __syncthreads() would also wait for the reference loads just issued
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    STAMP(12);
     float* sred = reinterpret_cast<float*>(smem) + wave * (2 * COUT);
+    // The second sum is taken against the raw reference value, sum(v * ref), and corrected per channel when the block's
+    // totals are formed: sum(v * xhat) = rstd * (sum(v * ref) - mean * sum(v)).
+    const bool full = ty0 + TH <= H && tx0 + TW <= W;      // every pixel of the patch is inside the image (block-uniform)
 #pragma unroll
     for (int i = 0; i < MQ; ++i) {
         const int q = i * 16 + g * 4;
         const f32x4 es = *reinterpret_cast<const f32x4*>(tab + q), eh = *reinterpret_cast<const f32x4*>(tab + COUT + q);
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(tab + 2 * COUT + q), rs = *reinterpret_cast<const f32x4*>(tab + 3 * COUT + q);
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        // ReLU mask as a number: clamp(2^64 * (ref * scale + shift)) is 1 for every positive pre-activation of at least
+        // 2^-64, 0 for zero, negatives and NaN: one packed fma with the clamp modifier per two elements
+        constexpr float BIG = 18446744073709551616.f;
+        const f32x2_t scb[2] = {{es[0] * BIG, es[1] * BIG}, {es[2] * BIG, es[3] * BIG}};
+        const f32x2_t shb[2] = {{eh[0] * BIG, eh[1] * BIG}, {eh[2] * BIG, eh[3] * BIG}};
 #pragma unroll
         for (int j = 0; j < MP; ++j) {
-            const float rf[4] = {bf_lo(rr[i][j].x), bf_hi(rr[i][j].x), bf_lo(rr[i][j].y), bf_hi(rr[i][j].y)};
+            const f32x2_t rf[2] = {{bf_lo(rr[i][j].x), bf_hi(rr[i][j].x)}, {bf_lo(rr[i][j].y), bf_hi(rr[i][j].y)}};
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float pre = fmaf(rf[e], es[e], eh[e]);
-                v[e] = (pok[j] && pre > 0.f) ? acc[i][j][e] : 0.f;
-                s1[e] += v[e];
-                s2[e] += v[e] * ((rf[e] - mu[e]) * rs[e]);
+            for (int h = 0; h < 2; ++h) {
+                f32x2_t m;
+                asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m) : "v"(rf[h]), "v"(scb[h]), "v"(shb[h]));
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int e = 2 * h + e2;
+                    v[e] = acc[i][j][e] * m[e2];
+                    if (!full) v[e] = pok[j] ? v[e] : 0.f;      // rows past the image edge were computed from padding
+                    s1[e] += v[e];
+                    s2[e] = fmaf(v[e], rf[h][e2], s2[e]);
+                }
             }
             if (pok[j] && (D3F_ABL != 3 || v[0] == 12345.678f)) *reinterpret_cast<uint2*>(yg + poff[j] * d.ldy + q) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
         }
@@ -264,13 +310,19 @@ __global__ __launch_bounds__(NT, 2) void dgrad3x3_fused_kernel(const dsaspp_conv
             *reinterpret_cast<f32x4*>(sred + COUT + q) = f32x4{s2[0], s2[1], s2[2], s2[3]};
         }
     }
+    STAMP(13);
     __syncthreads();
+    STAMP(14);
     if (tid < 2 * COUT) {
         const float* all = reinterpret_cast<const float*>(smem);
-        float t = 0.f;
-#pragma unroll
-        for (int w8 = 0; w8 < NT / 64; ++w8) t += all[w8 * 2 * COUT + tid];
         const int half = tid / COUT, q = tid - half * COUT;
+        float t = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < NT / 64; ++w8) {
+            t += all[w8 * 2 * COUT + tid];
+            t1 += all[w8 * 2 * COUT + q];              // sum(v) of the same channel
+        }
+        if (half) t = tab[3 * COUT + q] * fmaf(-tab[2 * COUT + q], t1, t);
         const int sld = d.s_ld > 0 ? d.s_ld : COUT;
         atomicAdd(d.s_acc + (size_t)(blockIdx.x % DS_R) * 2 * sld + half * sld + q, t);
     }
