@@ -88,8 +88,8 @@ void run(const char* name, const unsigned char* src, size_t window, size_t block
     float ms;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / 3, bytes = (double)blocks * steps * STAGE;
-    printf("%-46s depth %d bar %d reads %2d mfma %2d: %8.1f us  %6.2f TB/s  %5.1f B/clk/CU (2.4 GHz, %d CUs)\n", name, DEPTH, (int)BAR, NRD, NMF, us,
-           bytes / us / 1e6, bytes / blocks / (us * 1e-6 * 2.4e9), blocks);
+    printf("%-46s depth %d bar %d reads %2d mfma %2d: %8.1f us  %6.2f TB/s  %5.1f B/clk/CU (2.4 GHz, %d CUs)  %6.0f TFLOP/s of MFMA\n", name, DEPTH, (int)BAR, NRD,
+           NMF, us, bytes / us / 1e6, bytes / blocks / (us * 1e-6 * 2.4e9), blocks, (double)blocks * steps * 8 * NMF * 16384.0 / us / 1e6);
 }
 
 int main() {
@@ -109,10 +109,14 @@ int main() {
     L2C(3, true, 12, 0);
     L2C(3, true, 12, 16);
     L2C(3, false, 12, 16);
+    // the same stage and the same twelve fragment reads feeding twice the MFMAs: a 256 x 256 x 32 step (128 x 64 wave tiles)
+    L2C(3, true, 12, 32);
+    L2C(3, true, 12, 48);
     // ---- L2-resident, rows of a 4224-byte pitch (a slab), 16 K-steps per 256-row tile
 #define L2S(D, B, R, M) run<D, B, R, M>("L2 window 2 MiB, 4224-byte row pitch", src, (size_t)2 << 20, (size_t)256 * 4224, 4224, 128, 16, steps, out, blocks)
     L2S(3, true, 0, 0);
     L2S(3, true, 12, 16);
+    L2S(3, true, 12, 32);
     // ---- HBM stream, contiguous
 #define HBC(D, B, R, M) run<D, B, R, M>("HBM stream, contiguous stages", src, big, span_c / 4, 128, STAGE, 1 << 30, steps / 4, out, blocks)
     HBC(3, true, 0, 0);
