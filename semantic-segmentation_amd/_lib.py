@@ -145,6 +145,7 @@ def load():
     lib.dsaspp_last_error.restype = ctypes.c_char_p
     lib.dsaspp_version.restype = ctypes.c_int
     lib.dsaspp_source_hash.restype = ctypes.c_char_p
+    lib.dsaspp_conv_last_route.restype = ctypes.c_char_p
     for _, (_, struct, entry) in OPS.items():
         if entry is not None:
             fn = getattr(lib, entry)
@@ -180,6 +181,11 @@ def load():
 def source_hash():
     """Hash of the sources the loaded library was built from (dsaspp_source_hash)."""
     return load().dsaspp_source_hash().decode()
+
+
+def conv_last_route():
+    """Kernel family the calling thread's most recent convolution op went to (dsaspp_conv_last_route)."""
+    return load().dsaspp_conv_last_route().decode()
 
 
 def check(rc):

@@ -14,6 +14,8 @@ int dsaspp_set_error(const char* fmt, ...);
 
 // persistent grouped 1x1 data gradient (dgrad_group.hip): -1 = descriptor not of its form, 0 = launched
 int dsaspp_dgrad_group_launch(const dsaspp_conv_desc& d, hipStream_t s);
+// single-source slab data gradient with a long K on a 256 x 256 tile (dgrad_wide.hip): same return convention
+int dsaspp_dgrad_wide_launch(const dsaspp_conv_desc& d, hipStream_t s);
 // halo-patch 3x3 convolution with few output channels (conv3x3_halo.hip): same return convention
 int dsaspp_conv3x3_halo_launch(const dsaspp_conv_desc& d, hipStream_t s);
 

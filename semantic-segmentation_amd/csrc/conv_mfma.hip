@@ -675,6 +675,11 @@ int launch_multi(const dsaspp_conv_desc& d, hipStream_t s) { return launch_mode<
 
 }  // namespace
 
+// name of the kernel family the calling thread's most recent convolution was routed to
+static thread_local const char* conv_route = "";
+
+extern "C" const char* dsaspp_conv_last_route(void) { return conv_route; }
+
 extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t stream) {
     DS_REQUIRE(dp != nullptr, "conv_fwd: null descriptor");
     const dsaspp_conv_desc& d = *dp;
@@ -705,9 +710,13 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
     DS_REQUIRE(d.dtype == 0 || d.dtype == 1, "conv_fwd: dtype must be 0 (bf16) or 1 (fp32)");
     if (d.gx_corr1) {
         DS_REQUIRE(d.dtype == 0, "conv_fwd: the gradient read-out prologue is a bf16 form");
+        conv_route = "dgrad3x3_fused";
         return dsaspp_dgrad3x3_fused_launch(d, s);
     }
-    if (d.dtype == 1) return dsaspp_f32_conv(d, s);
+    if (d.dtype == 1) {
+        conv_route = "f32";
+        return dsaspp_f32_conv(d, s);
+    }
     if (d.n_src > 1) {
         DS_REQUIRE(d.n_src <= 4, "conv_fwd: at most 4 sources (got %d)", d.n_src);
         DS_REQUIRE(d.g && d.epi_relu && d.taps == 1 && d.ref && d.e_scale && d.e_shift && d.e_mean && d.e_rstd && !d.in_scale && !d.in_mask && !d.in_relu && !d.bias && !d.out_mask,
@@ -717,27 +726,37 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
         DS_REQUIRE((((uintptr_t)d.x1 | (uintptr_t)d.w1 | (uintptr_t)d.x2 | (uintptr_t)d.w2 | (uintptr_t)d.x3 | (uintptr_t)d.w3) & 15) == 0,
                    "conv_fwd: operands must be 16-byte aligned");
         const int rc = dsaspp_dgrad_group_launch(d, s);
+        conv_route = rc >= 0 ? "dgrad_group" : "multi_source";
         return rc >= 0 ? rc : launch_multi(d, s);
     }
     // slab data gradients of the masked form: persistent DMA-fed kernel.  The narrow ones too (48..144 channels a group of
     // dense layers produced itself): they are bound by the slab traffic, which that kernel keeps in flight across tiles
     // (DSASPP_DGG_MIN_COUT overrides the threshold for A/B measurements).
     static const int dgg_min_cout = [] { const char* e = getenv("DSASPP_DGG_MIN_COUT"); return e ? atoi(e) : 48; }();
+    if (d.g) {           // wide single-source slab data gradients (transitions, ASPP 1x1): 256 x 256 tile
+        conv_route = "dgrad_wide";
+        const int rc = dsaspp_dgrad_wide_launch(d, s);
+        if (rc >= 0) return rc;
+    }
     if (d.g && d.cout >= dgg_min_cout) {
+        conv_route = "dgrad_group";
         const int rc = dsaspp_dgrad_group_launch(d, s);
         if (rc >= 0) return rc;
     }
     if (d.taps == 9) {   // narrow-output 3x3 with a small dilation: halo-patch kernel (DSASPP_NO_HALO=1 disables it)
         static const int off = [] { const char* e = getenv("DSASPP_NO_HALO"); return e ? atoi(e) : 0; }();
         if (!off) {
+            conv_route = "conv3x3_halo";
             const int rc = dsaspp_conv3x3_halo_launch(d, s);
             if (rc >= 0) return rc;
         }
     }
     if (d.taps == 1) {   // BN-ReLU-1x1 forward with few output channels: streaming kernel (DSASPP_STREAM1X1=0 disables it)
+        conv_route = "conv1x1_stream";
         const int rc = dsaspp_conv1x1_stream_launch(d, s);
         if (rc >= 0) return rc;
     }
+    conv_route = "conv_tile";
     const int co = d.cout;
     {   // experiment hook: DSASPP_CONV_TILE=<id> forces a tile for launches with cout > 64
         static const int forced = [] { const char* e = getenv("DSASPP_CONV_TILE"); return e ? atoi(e) : 0; }();

@@ -13,7 +13,7 @@ CLASSES = ['untimed',
            'conv_kernel<128,64,2,2>', 'conv_kernel<128,32,4,1>',
            'wgrad_kernel<64,192,1,4>', 'wgrad_kernel<192,128,4,2>', 'wgrad_kernel<128,128,2,4>',
            'upce_kernel<19>', 'wgrad_kernel<48,192,1,4>', 'wgrad_kernel<32,192,1,4>', 'dgrad_group_kernel', 'conv3x3_halo_kernel',
-           'conv1x1_stream_kernel<192>', 'conv1x1_stream_kernel<128>', 'wgrad_group_kernel', 'dgrad3x3_fused_kernel']
+           'conv1x1_stream_kernel<192>', 'conv1x1_stream_kernel<128>', 'wgrad_group_kernel', 'dgrad3x3_fused_kernel', 'dgrad_wide_kernel']
 
 
 def kernel_class(kind, f):
@@ -21,6 +21,11 @@ def kernel_class(kind, f):
         co = f['cout']
         if f.get('gx_corr1') is not None:
             return 17
+        if (f.get('g') is not None and (f.get('n_src') or 0) <= 1 and f.get('g_bf16') and f['taps'] == 1 and f.get('epi_relu') == 1
+                and f.get('ref') is not None and f.get('e_scale') is not None and f.get('e_mean') is not None and f.get('in_scale') is None
+                and f.get('in_mask') is None and not f.get('in_relu') and f.get('bias') is None and f.get('out_mask') is None
+                and not f.get('dtype') and f['cin'] >= 256 and co >= 512 and co % 4 == 0 and os.environ.get('DSASPP_DGRAD_WIDE', '1') != '0'):
+            return 18
         if (f.get('n_src') or 0) > 1 or (
                 f.get('g') is not None and co >= int(os.environ.get('DSASPP_DGG_MIN_COUT', 48)) and f['taps'] == 1 and f.get('epi_relu') and f.get('ref') is not None
                 and f.get('e_scale') is not None and f.get('e_mean') is not None and f.get('in_scale') is None

@@ -4,7 +4,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from optools import Ref, bf, close, run_both  # noqa: E402
+from optools import Ref, bf, close, pkg, run_both  # noqa: E402
 
 R = 16
 
@@ -154,6 +154,20 @@ def test_dgrad_group_many_tiles(n_src, cin, g_bf16, g_acc, stats, monkeypatch):
     monkeypatch.setenv('DSASPP_DGG_GRID', '8')
     f = multi_source_fields(n_src, n=3, H=20, W=33, cin=cin, cout=328, sld=400, g_bf16=g_bf16, g_acc=g_acc, stats=stats)
     check_multi_source(f, n_src, stats)
+
+
+@pytest.mark.parametrize('cin,cout,g_acc,stats,grid', [
+    (256, 520, True, True, 8), (272, 520, False, True, 8), (264, 776, True, False, 8), (1104, 552, True, True, 8),
+    (320, 1024, True, True, 0), (1056, 512, False, True, 16)])
+def test_dgrad_wide(cin, cout, g_acc, stats, grid, monkeypatch):
+    """The 256 x 256-tile data-gradient kernel (one source, long K, wide slab: the transitions and the ASPP 1x1
+    layers): K tails of 8, 16 and 24 channels past a 32-channel step, partial pixel and channel tiles, blocks that
+    walk several (pixel tile, channel tile) pairs and blocks that get none, slab overwritten and accumulated."""
+    if grid:
+        monkeypatch.setenv('DSASPP_DGG_GRID', str(grid))
+    f = multi_source_fields(1, n=3, H=24, W=33, cin=cin, cout=cout, sld=cout + 72, g_bf16=True, g_acc=g_acc, stats=stats)
+    check_multi_source(f, 1, stats)
+    assert pkg._lib.conv_last_route() == 'dgrad_wide'
 
 
 def test_conv_s_slice():

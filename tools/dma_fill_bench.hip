@@ -22,7 +22,8 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // DEPTH stages in flight, ring of DEPTH + 1 slots.  row_stride: bytes between the 256 rows of a stage (128 = the stage
 // is one contiguous 32 KiB block); a stage advances step_stride bytes per step for `ksteps` steps, then the next 256
 // rows follow.  window: the source wraps at this many bytes (small: L2 resident; 0: no wrap, HBM stream).
-template <int DEPTH, bool BAR, int NRD, int NMF>
+// SEG: bytes a stage takes from each row (128: 8 rows per DMA instruction, 64: 16 rows of half a cache line each)
+template <int DEPTH, bool BAR, int NRD, int NMF, int SEG = 128>
 __global__ __launch_bounds__(512, 2) void fill(const unsigned char* __restrict__ src, const size_t window, const size_t block_span,
                                                const int row_stride, const int step_stride, const int ksteps, const int steps, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -35,8 +36,9 @@ __global__ __launch_bounds__(512, 2) void fill(const unsigned char* __restrict__
         const int tile = c_step / ksteps, kk = c_step - tile * ksteps;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = (i * 8 + wave) * 8 + (lane >> 3);
-            size_t off = base + ((size_t)tile * 256 + row) * row_stride + (size_t)kk * step_stride + (lane & 7) * 16;
+            constexpr int LPR = SEG / 16, RPI = 64 / LPR;              // lanes per row, rows per instruction
+            const int row = (i * 8 + wave) * RPI + lane / LPR;
+            size_t off = base + ((size_t)tile * (32 * RPI) + row) * row_stride + (size_t)kk * step_stride + (lane % LPR) * 16;
             if (window) off %= window;
             const unsigned char* p = src + off;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
@@ -71,9 +73,9 @@ __global__ __launch_bounds__(512, 2) void fill(const unsigned char* __restrict__
     if (t == 12345.678f) out[blockIdx.x * 512 + tid] = t;
 }
 
-template <int DEPTH, bool BAR, int NRD, int NMF>
+template <int DEPTH, bool BAR, int NRD, int NMF, int SEG = 128>
 void run(const char* name, const unsigned char* src, size_t window, size_t block_span, int row_stride, int step_stride, int ksteps, int steps, float* out, int blocks) {
-    auto kern = fill<DEPTH, BAR, NRD, NMF>;
+    auto kern = fill<DEPTH, BAR, NRD, NMF, SEG>;
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const size_t lds = (size_t)(DEPTH + 1) * STAGE;
     hipEvent_t e0, e1;
@@ -117,6 +119,10 @@ int main() {
     L2S(3, true, 0, 0);
     L2S(3, true, 12, 16);
     L2S(3, true, 12, 32);
+    // ---- the same with 64 bytes per row and step (a 512-row stage of a 256 x 256 x 32 step): half cache lines
+#define L2H(D, B, R, M) run<D, B, R, M, 64>("L2 window 2 MiB, 4224-byte pitch, 64 B per row", src, (size_t)2 << 20, (size_t)512 * 4224, 4224, 64, 32, steps, out, blocks)
+    L2H(3, true, 0, 0);
+    L2H(3, true, 12, 32);
     // ---- HBM stream, contiguous
 #define HBC(D, B, R, M) run<D, B, R, M>("HBM stream, contiguous stages", src, big, span_c / 4, 128, STAGE, 1 << 30, steps / 4, out, blocks)
     HBC(3, true, 0, 0);
@@ -125,5 +131,8 @@ int main() {
 #define HBS(D, B, R, M) run<D, B, R, M>("HBM stream, 4224-byte row pitch", src, big, (size_t)(steps / 4 / 16) * 256 * 4224, 4224, 128, 16, steps / 4, out, blocks)
     HBS(3, true, 0, 0);
     HBS(3, true, 12, 16);
+#define HBH(D, B, R, M) run<D, B, R, M, 64>("HBM stream, 4224-byte pitch, 64 B per row", src, big, (size_t)(steps / 4 / 32) * 512 * 4224, 4224, 64, 32, steps / 4, out, blocks)
+    HBH(3, true, 0, 0);
+    HBH(3, true, 12, 32);
     return 0;
 }
