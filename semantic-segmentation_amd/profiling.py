@@ -133,12 +133,13 @@ def tag_program_fine(prog, table):
     return per
 
 
-def tag_program(prog):
-    """Tag every MFMA / loss op of a HipProgram for event timing; returns per-class (flops, bytes) per run."""
+def tag_program(prog, only=None):
+    """Tag every MFMA / loss op of a HipProgram (or those of kernel class `only`) for event timing; returns per-class
+    (flops, bytes, launches) per run."""
     per = {}
     for i, (kind, f) in enumerate(prog.keepalive):
         t = kernel_class(kind, f)
-        if t:
+        if t and (only is None or t == only):
             prog.set_tag(i, t)
             fl, by = work(kind, f)
             a = per.setdefault(t, [0.0, 0.0, 0])
