@@ -236,3 +236,25 @@ def test_kernels_on_a_slab_past_4GiB():
     assert torch.isfinite(got.float()).all() and float(want.float().abs().max()) > 0
     assert torch.equal(got, want)
     assert bool((gs.view(M, LD)[M - tail:, CIN:] == 0).all())        # channels past cout untouched
+
+    # ---- single-source slab data gradient with a long K: the 256 x 256-tile kernel addresses the slab by 32-bit byte
+    #      offsets and must leave a slab this large to the 128 x 128 kernel; the tail problem (small offsets) runs on it
+    import sys
+    lib = sys.modules['semantic_segmentation_amd']._lib
+    KW = 256
+    dyw = torch.randn(M * KW, device='cuda', generator=g).to(torch.bfloat16)
+    ww = (torch.randn(CIN * KW, device='cuda', generator=g) * KW ** -0.5).to(torch.bfloat16)
+    gs.zero_()
+    gs_t.zero_()
+    d1 = dict(_CONV, n_img=n, H=H, W=W, cin=KW, cout=CIN, taps=1, dil=1, x=Ref(dyw), ldx=KW, w=Ref(ww), epi_relu=1,
+              ref=Ref(slab), ldref=LD, e_scale=Ref(es[0]), e_shift=Ref(eh[0]), e_mean=Ref(mean), e_rstd=Ref(rstd),
+              s_acc=Ref(acc[0]), g=Ref(gs), ldg=LD, g_accumulate=0, g_bf16=1)
+    be.call('conv', **d1)
+    assert lib.conv_last_route() == 'dgrad_group'
+    be.call('conv', **dict(d1, H=8, x=Ref(dyw, (M - tail) * KW), ref=Ref(slab, off), g=Ref(gs_t)))
+    assert lib.conv_last_route() == 'dgrad_wide'
+    torch.cuda.synchronize()
+    got = gs.view(M, LD)[M - tail:, :CIN].float()
+    want = gs_t.view(tail, LD)[:, :CIN].float()
+    assert torch.isfinite(got).all() and float(want.abs().max()) > 0
+    assert float((got - want).abs().max()) <= 2e-2 * float(want.abs().max())      # two kernels, one bf16 rounding apart at most

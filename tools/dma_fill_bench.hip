@@ -8,6 +8,10 @@
 #include <cstdio>
 #include <cstdlib>
 
+#ifndef DMA_MOD
+#define DMA_MOD ""        // cache-policy modifiers of the DMA instruction for experiments: -DDMA_MOD='" sc0"', '" sc1"', '" nt"', '" sc0 sc1"'
+#endif
+
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -41,7 +45,7 @@ __global__ __launch_bounds__(512, 2) void fill(const unsigned char* __restrict__
             size_t off = base + ((size_t)tile * (32 * RPI) + row) * row_stride + (size_t)kk * step_stride + (lane % LPR) * 16;
             if (window) off %= window;
             const unsigned char* p = src + off;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" DMA_MOD
                          : : "s"(ring_l + c_slot * STAGE + (i * 8 + wave) * 1024), "v"(p) : "memory");
         }
         ++c_step;
