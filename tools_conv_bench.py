@@ -19,6 +19,7 @@ g16 = torch.zeros(M*LD, device=dev).to(bf)
 y1 = torch.randn(M*192, device=dev).to(bf)
 dz48 = torch.randn(M*48, device=dev).to(bf)
 y512 = torch.randn(M*512, device=dev).to(bf); w512 = (torch.randn(2112*512, device=dev)*0.03).to(bf)
+y1104 = torch.randn(M*1104, device=dev).to(bf); w1104 = (torch.randn(2112*1104, device=dev)*0.03).to(bf)
 y1b, y1c, y1d = (torch.randn(M*192, device=dev).to(bf) for _ in range(3))
 acc1, acc2, acc3 = (torch.zeros(R*2*LD, device=dev) for _ in range(3))
 dr = torch.zeros(M*192, device=dev)
@@ -48,6 +49,7 @@ cases = {
  'slab_noS_noref': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), g=Ref(g), ldg=LD, g_accumulate=1),
  'slab_store_only': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), g=Ref(g), ldg=LD, g_accumulate=0),
  'aspp_dgrad': conv(n_img=n, H=H, W=W, cin=512, cout=2112, taps=1, dil=1, x=Ref(y512), ldx=512, w=Ref(w512), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc), g=Ref(g16), ldg=LD, g_accumulate=1, g_bf16=1),
+ 'trans_dgrad': conv(n_img=n, H=H, W=W, cin=1104, cout=2112, taps=1, dil=1, x=Ref(y1104), ldx=1104, w=Ref(w1104), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc), g=Ref(g16), ldg=LD, g_accumulate=1, g_bf16=1),
  'slab_multi4': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc), g=Ref(g), ldg=LD, g_accumulate=1,
                      n_src=4, x1=Ref(y1b), w1=Ref(w1t), es1=Ref(sc1), eh1=Ref(sh1), sa1=Ref(acc1), x2=Ref(y1c), w2=Ref(w1t), es2=Ref(sc1), eh2=Ref(sh1), sa2=Ref(acc2), x3=Ref(y1d), w3=Ref(w1t), es3=Ref(sc1), eh3=Ref(sh1), sa3=Ref(acc3)),
  'slab_multi4_16': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc), g=Ref(g16), ldg=LD, g_accumulate=1, g_bf16=1,
