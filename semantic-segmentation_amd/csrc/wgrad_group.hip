@@ -121,28 +121,31 @@ __global__ __launch_bounds__(NT, 2) void wgrad_group_kernel(const WGArgs a) {
     // ---- dz DMA: wave w issues instructions t*8 + w (t < Z_PER_WAVE) of the tile's Z_INSTR; LDS chunk p = instr*64 + lane
     //      holds (row p / ZRC, data chunk p % ZRC), the padding chunk repeats the row's last data chunk
     const uint32_t zring_l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)zring);
-    uint32_t zd[Z_PER_WAVE];                          // row << 16 | byte offset of the chunk inside the row
+    //      Row and chunk of a lane's Z_PER_WAVE instructions are recomputed at every request (a division by a constant,
+    //      from an opaque copy of the lane id so that the compiler does not hoist them back out of the K-loop) instead of
+    //      being kept in eight registers: with four sources of 192 output channels the accumulators alone take 192, one
+    //      accumulator tile went to scratch, and its reload inside the K-loop -- waited for with vmcnt(0) -- drained the DMA
+    //      queue at every stage.  tools_check_isa.py reports scratch accesses and vmcnt(0) waits inside MFMA loops.
     const int zch_ok = (a.cout + 7) / 8;              // data chunks that exist in a dz row
-#pragma unroll
-    for (int t = 0; t < Z_PER_WAVE; ++t) {
-        const int p = (t * NW + wave) * 64 + lane;
-        const int row = p / ZRC;
-        int cc = p - row * ZRC;
-        cc = cc < zch_ok ? cc : zch_ok - 1;
-        zd[t] = ((uint32_t)(row < BKP ? row : BKP - 1) << 16) | ((uint32_t)cc * 16u);
-    }
     constexpr int ZMIN = Z_INSTR / NW;                   // DMA instructions every wave issues per tile (some issue one more)
     int d_stage = 0, d_k = 0, d_s = 0;                   // DMA cursor; frozen on the last tile once it is reached
     auto issue_z = [&]() {
         const u16* base = a.dz[d_s];
         const int m0 = m_begin + d_k * BKP;
         const uint32_t slot_l = zring_l + (uint32_t)(d_stage % NZ) * Z_BYTES;
+        int lane_z = lane;                            // opaque copy: otherwise the rows and chunks below are hoisted out of the
+        asm volatile("" : "+v"(lane_z));              // K-loop as eight loop-invariant registers
 #pragma unroll
         for (int t = 0; t < Z_PER_WAVE; ++t) {
             if (WGG_ABL != 3 && t * NW + wave < Z_INSTR) {
-                int m = m0 + (int)(zd[t] >> 16);
+                const int p = (t * NW + wave) * 64 + lane_z;
+                int row = p / ZRC;
+                int cc = p - row * ZRC;
+                cc = cc < zch_ok ? cc : zch_ok - 1;
+                row = row < BKP ? row : BKP - 1;
+                int m = m0 + row;
                 m = m < M ? m : M - 1;
-                const uint32_t off = (uint32_t)m * (uint32_t)a.lddz * 2u + (zd[t] & 0xffffu);
+                const uint32_t off = (uint32_t)m * (uint32_t)a.lddz * 2u + (uint32_t)cc * 16u;
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                              : : "s"(slot_l + (uint32_t)(t * NW + wave) * 1024u), "v"(off), "s"(base) : "memory");
             }
