@@ -221,7 +221,10 @@ __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
         const uint32_t qoff = (uint32_t)(qok ? qw : 0) * 2u, ldref2 = (uint32_t)a.ldref * 2u, ldg2 = (uint32_t)a.ldg * 2u;
         const unsigned char* refb = reinterpret_cast<const unsigned char*>(a.ref);
         unsigned char* gb = reinterpret_cast<unsigned char*>(a.g);
-        constexpr int EARLY = 2, AHEAD = ACCG ? 5 : NGRP;    // groups requested before the last K-step / in flight at most
+        // groups requested before the last K-step / in flight at most.  Accumulating (two loads per pass), three groups are
+        // what fits beside the accumulators without a spill; with five, 17 registers went to scratch, every reload was
+        // waited for with vmcnt(0) -- which also waits for the whole prefetch -- and the launches took 6-8 % longer
+        constexpr int EARLY = 2, AHEAD = ACCG ? 3 : NGRP;
         u32x2 rfv[NGRP][NRP], gov[ACCG ? NGRP : 1][NRP];
         auto load_group = [&](const int j) {
             int pj = p_w + j * 16;
