@@ -755,6 +755,9 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
         conv_route = "conv1x1_stream";
         const int rc = dsaspp_conv1x1_stream_launch(d, s);
         if (rc >= 0) return rc;
+        conv_route = "conv_wide";                    // many output channels, long K (transitions, ASPP 1x1): 256 x 256 tile
+        const int rcw = dsaspp_conv_wide_launch(d, s);
+        if (rcw >= 0) return rcw;
     }
     conv_route = "conv_tile";
     const int co = d.cout;

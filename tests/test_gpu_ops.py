@@ -170,6 +170,23 @@ def test_dgrad_wide(cin, cout, g_acc, stats, grid, monkeypatch):
     assert pkg._lib.conv_last_route() == 'dgrad_wide'
 
 
+@pytest.mark.parametrize('cin,cout,kw', [
+    (1104, 512, dict(stats=True, grid=8)),                        # K tail of 16 channels, two full channel tiles
+    (520, 456, dict(stats=True, ldx=544, ldy=520, yoff=8)),       # K tail of 8, partial channel tile, strided in and out
+    (512, 1056, dict(bias=True, grid=8)),                         # five channel tiles, the last one 32 wide; no statistics
+    (2112, 776, dict(stats=True, relu=False)),                    # long K, no ReLU
+    (768, 1104, dict(stats=True, bias=True, grid=16))])
+def test_conv_wide(cin, cout, kw, monkeypatch):
+    """BN-ReLU-1x1 forward on the 256 x 256 tile (transitions, ASPP 1x1 layers): pixel operand through registers with the
+    prologue applied two steps ahead, K tails, partial pixel and channel tiles, several tiles per block, statistics."""
+    kw = dict(kw)
+    grid = kw.pop('grid', 0)
+    if grid:
+        monkeypatch.setenv('DSASPP_DGG_GRID', str(grid))
+    check_conv(conv_fields(n=3, H=24, W=33, cin=cin, cout=cout, taps=1, dil=1, seed=300 + cin, **kw))
+    assert pkg._lib.conv_last_route() == 'conv_wide'
+
+
 def test_conv_s_slice():
     f = conv_fields(n=2, H=10, W=12, cin=192, cout=96, taps=1, dil=1, scale=False, relu=False, epi_relu=True,
                     e_scale=True, s_acc=True, g=True, g_acc=True, ldy=400, yoff=8, seed=77)
