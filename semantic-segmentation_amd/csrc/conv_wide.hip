@@ -82,9 +82,10 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
         q_base = (r - ptl * nQ) * BQ;
     };
 
+    // (without a scale / shift pair the table holds 1 and 0: x * 1 + 0 is exact, the layer is ReLU -> conv or a plain GEMM)
     for (int c = tid; c < cinp; c += NT) {
-        tab[c] = c < cin ? a.sc[c] : 0.f;
-        tab[cinp + c] = c < cin ? a.sh[c] : 0.f;
+        tab[c] = c < cin ? (a.sc ? a.sc[c] : 1.f) : 0.f;
+        tab[cinp + c] = (c < cin && a.sh) ? a.sh[c] : 0.f;
     }
 
     // ---- operand cursor (two steps ahead of the arithmetic).  Filter rows: DMA instruction i of a wave fills stage rows
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
 int dsaspp_conv_wide_launch(const dsaspp_conv_desc& d, hipStream_t s) {
     static const int enabled = [] { const char* e = getenv("DSASPP_CONV_WIDE"); return e ? atoi(e) : 1; }();
     if (!enabled) return -1;
-    const bool form = d.taps == 1 && d.y && !d.y_f32 && !d.g && !d.epi_relu && !d.s_acc && d.in_scale && d.in_shift && !d.in_mask &&
+    const bool form = d.taps == 1 && d.y && !d.y_f32 && !d.g && !d.epi_relu && !d.s_acc && ((d.in_scale != nullptr) == (d.in_shift != nullptr)) && !d.in_mask &&
                       (d.in_relu == 0 || d.in_relu == 1) && !d.out_mask && d.n_src <= 1 && d.dtype == 0 && !d.gx_corr1 && d.cin % 8 == 0 &&
                       d.ldx % 8 == 0 && d.cout % 4 == 0 && d.ldy % 4 == 0;
     if (!form) return -1;

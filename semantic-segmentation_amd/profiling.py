@@ -41,7 +41,7 @@ def kernel_class(kind, f):
                 and not f.get('epi_relu') and f.get('s_acc') is None and f.get('g') is None and f['cin'] >= 64
                 and not f.get('dtype')):
             return 14 if co > 128 else 15      # streaming BN-ReLU-1x1 forward (conv1x1_stream.hip)
-        if (f['taps'] == 1 and f.get('in_scale') is not None and f.get('in_relu') in (0, 1) and f.get('in_mask') is None
+        if (f['taps'] == 1 and f.get('in_relu') in (0, 1, None) and f.get('in_mask') is None
                 and f.get('out_mask') is None and not f.get('y_f32') and not f.get('epi_relu') and f.get('s_acc') is None
                 and f.get('g') is None and f['cin'] >= 512 and co >= 448 and co % 4 == 0 and not f.get('dtype')
                 and (f.get('n_src') or 0) <= 1 and os.environ.get('DSASPP_CONV_WIDE', '1') != '0'):

@@ -175,7 +175,8 @@ def test_dgrad_wide(cin, cout, g_acc, stats, grid, monkeypatch):
     (520, 456, dict(stats=True, ldx=544, ldy=520, yoff=8)),       # K tail of 8, partial channel tile, strided in and out
     (512, 1056, dict(bias=True, grid=8)),                         # five channel tiles, the last one 32 wide; no statistics
     (2112, 776, dict(stats=True, relu=False)),                    # long K, no ReLU
-    (768, 1104, dict(stats=True, bias=True, grid=16))])
+    (768, 1104, dict(stats=True, bias=True, grid=16)),
+    (1104, 512, dict(stats=True, scale=False))])                  # ReLU -> conv without BatchNorm in front (first ASPP branch)
 def test_conv_wide(cin, cout, kw, monkeypatch):
     """BN-ReLU-1x1 forward on the 256 x 256 tile (transitions, ASPP 1x1 layers): pixel operand through registers with the
     prologue applied two steps ahead, K tails, partial pixel and channel tiles, several tiles per block, statistics."""
