@@ -115,8 +115,8 @@ typedef struct dsaspp_conv_desc {
 } dsaspp_conv_desc;
 
 int dsaspp_conv_fwd(const dsaspp_conv_desc* d, dsaspp_stream_t stream);
-/* Name of the kernel family the calling thread's most recent dsaspp_conv_fwd was routed to ("dgrad_wide",
- * "dgrad_group", "conv3x3_halo", "conv_tile", ...; "" before the first call).  No counterpart in the reference: a
+/* Name of the kernel family the calling thread's most recent dsaspp_conv_fwd or dsaspp_conv_wgrad was routed to
+ * ("dgrad_wide", "dgrad_group", "conv3x3_halo", "conv_tile", "wgrad_wide", "wgrad_tile", ...; "" before the first call).  No counterpart in the reference: a
  * diagnostic, so that a test of one kernel can tell that its case did not quietly take another route. */
 const char* dsaspp_conv_last_route(void);
 

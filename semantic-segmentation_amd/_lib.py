@@ -184,7 +184,7 @@ def source_hash():
 
 
 def conv_last_route():
-    """Kernel family the calling thread's most recent convolution op went to (dsaspp_conv_last_route)."""
+    """Kernel family the calling thread's most recent convolution or weight-gradient op went to (dsaspp_conv_last_route)."""
     return load().dsaspp_conv_last_route().decode()
 
 

@@ -27,6 +27,11 @@ int dsaspp_dgrad3x3_fused_launch(const dsaspp_conv_desc& d, hipStream_t s);
 // grouped 1x1 weight gradient of layers that share their input (wgrad_group.hip); 0 = launched, else an error code
 int dsaspp_wgrad_group_launch(const dsaspp_wgrad_desc& d, hipStream_t s);
 
+// 1x1 weight gradient with many input and output channels on a 256 x 256 tile (wgrad_wide.hip): -1 = not of its form, 0 = launched
+int dsaspp_wgrad_wide_launch(const dsaspp_wgrad_desc& d, hipStream_t s);
+// records the kernel family of the calling thread's most recent convolution / weight-gradient op (dsaspp_conv_last_route)
+void dsaspp_note_route(const char* name);
+
 // streaming BN-ReLU-1x1 forward for cout <= 192 (conv1x1_stream.hip): same return convention
 int dsaspp_conv1x1_stream_launch(const dsaspp_conv_desc& d, hipStream_t s);
 

@@ -675,8 +675,10 @@ int launch_multi(const dsaspp_conv_desc& d, hipStream_t s) { return launch_mode<
 
 }  // namespace
 
-// name of the kernel family the calling thread's most recent convolution was routed to
+// name of the kernel family the calling thread's most recent convolution or weight gradient was routed to
 static thread_local const char* conv_route = "";
+
+void dsaspp_note_route(const char* name) { conv_route = name; }
 
 extern "C" const char* dsaspp_conv_last_route(void) { return conv_route; }
 

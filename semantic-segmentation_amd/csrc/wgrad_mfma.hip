@@ -344,8 +344,22 @@ extern "C" int dsaspp_conv_wgrad(const dsaspp_wgrad_desc* dp, dsaspp_stream_t st
     DS_REQUIRE((d.in_scale == nullptr) == (d.in_shift == nullptr), "conv_wgrad: in_scale/in_shift must come together");
     if (d.in_mask) DS_REQUIRE(d.in_mask_ld % 4 == 0, "conv_wgrad: in_mask_ld must be a multiple of 4");
     DS_REQUIRE(d.dtype == 0 || d.dtype == 1, "conv_wgrad: dtype must be 0 (bf16) or 1 (fp32)");
-    if (d.dtype == 1) return dsaspp_f32_wgrad(d, s);
-    if (d.n_src >= 2) return dsaspp_wgrad_group_launch(d, s);
+    if (d.dtype == 1) {
+        dsaspp_note_route("wgrad_f32");
+        return dsaspp_f32_wgrad(d, s);
+    }
+    if (d.n_src >= 2) {
+        dsaspp_note_route("wgrad_group");
+        return dsaspp_wgrad_group_launch(d, s);
+    }
+    if (d.taps == 1) {
+        const int rc = dsaspp_wgrad_wide_launch(d, s);      // many input and output channels (transitions, ASPP 1x1): 256 x 256 tile
+        if (rc >= 0) {
+            dsaspp_note_route("wgrad_wide");
+            return rc;
+        }
+    }
+    dsaspp_note_route("wgrad_tile");
     const int co = d.cout;
     if (co <= 32) return launch<32, 192, 1, 4>(d, s);
     if (co <= 48) return launch<48, 192, 1, 4>(d, s);

@@ -13,7 +13,8 @@ CLASSES = ['untimed',
            'conv_kernel<128,64,2,2>', 'conv_kernel<128,32,4,1>',
            'wgrad_kernel<64,192,1,4>', 'wgrad_kernel<192,128,4,2>', 'wgrad_kernel<128,128,2,4>',
            'upce_kernel<19>', 'wgrad_kernel<48,192,1,4>', 'wgrad_kernel<32,192,1,4>', 'dgrad_group_kernel', 'conv3x3_halo_kernel',
-           'conv1x1_stream_kernel<192>', 'conv1x1_stream_kernel<128>', 'wgrad_group_kernel', 'dgrad3x3_fused_kernel', 'dgrad_wide_kernel', 'conv_wide_kernel']
+           'conv1x1_stream_kernel<192>', 'conv1x1_stream_kernel<128>', 'wgrad_group_kernel', 'dgrad3x3_fused_kernel', 'dgrad_wide_kernel', 'conv_wide_kernel',
+           'wgrad_wide_kernel']
 
 
 def kernel_class(kind, f):
@@ -58,6 +59,9 @@ def kernel_class(kind, f):
         co = f['cout']
         if (f.get('n_src') or 0) > 1:
             return 16
+        if (f['taps'] == 1 and f.get('in_mask') is None and f.get('in_relu') in (0, 1, None) and f['cin'] >= 512 and co >= 448
+                and not f.get('dtype') and os.environ.get('DSASPP_WGRAD_WIDE', '1') != '0'):
+            return 20
         if co <= 32:
             return 11
         if co <= 48:

@@ -271,6 +271,23 @@ def test_wgrad_group(case):
         close(out[name][0], out[name][1], 5e-3, 'wgrad_group.' + name)
 
 
+@pytest.mark.parametrize('cin,cout,kw', [
+    (1104, 512, dict()),                                   # 19 pixel ranges of 128, the last one 72 rows; input-channel tail of 80
+    (520, 456, dict(ldx=544, lddz=520)),                   # both channel tiles partial (8 and 200 wide), strided operands
+    (512, 1056, dict(ksplit=1, relu=False)),               # one pixel range of 76 steps, fifth output tile 32 wide, no ReLU
+    (2112, 776, dict(scale=False)),                        # ReLU only (first ASPP branch), nine input tiles
+    (768, 1104, dict(ksplit=3))])
+def test_wgrad_wide(cin, cout, kw):
+    """1x1 weight gradient on the 256 x 256 tile (transitions, ASPP 1x1 layers): dz by LDS-DMA, x through registers with
+    the prologue applied two steps ahead, transposing fragment reads of unpadded swizzled rows; pixel ranges whose last
+    rows are past the end, partial channel tiles on both sides."""
+    f = wgrad_fields(n=3, H=24, W=33, cin=cin, cout=cout, taps=1, dil=1, seed=500 + cin, **kw)
+    out = run_both('wgrad', f)
+    assert float(out['dw'][0].abs().max()) > 0
+    close(out['dw'][0], out['dw'][1], 5e-3, 'wgrad_wide.dw')
+    assert pkg._lib.conv_last_route() == 'wgrad_wide'
+
+
 @pytest.mark.parametrize('case', range(len(WGRAD_CASES)))
 def test_wgrad(case):
     f = wgrad_fields(seed=case, **WGRAD_CASES[case])

@@ -59,6 +59,8 @@ cases = {
  'slab_multi2': conv(n_img=n, H=H, W=W, cin=192, cout=CIN, taps=1, dil=1, x=Ref(y1), ldx=192, w=Ref(w1t), epi_relu=1, ref=Ref(slab), ldref=LD, e_scale=Ref(sc1), e_shift=Ref(sh1), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc), g=Ref(g), ldg=LD, g_accumulate=1,
                      n_src=2, x1=Ref(y1b), w1=Ref(w1t), es1=Ref(sc1), eh1=Ref(sh1), sa1=Ref(acc1)),
  'wgrad1x1': ('wgrad', dict(n_img=n, H=H, W=W, cin=CIN, cout=192, taps=1, dil=1, x=Ref(slab), ldx=LD, in_scale=Ref(sc1), in_shift=Ref(sh1), in_relu=1, in_mask=None, in_mask_ld=0, dz=Ref(y1), lddz=192, dw=Ref(dw1), ksplit=0)),
+ 'trans_wgrad': ('wgrad', dict(n_img=n, H=H, W=W, cin=CIN, cout=1104, taps=1, dil=1, x=Ref(slab), ldx=LD, in_scale=Ref(sc1), in_shift=Ref(sh1), in_relu=1, in_mask=None, in_mask_ld=0, dz=Ref(y1104), lddz=1104, dw=Ref(torch.zeros(1104*CIN, device=dev)), ksplit=0)),
+ 'aspp_wgrad': ('wgrad', dict(n_img=n, H=H, W=W, cin=CIN, cout=512, taps=1, dil=1, x=Ref(slab), ldx=LD, in_scale=Ref(sc1), in_shift=Ref(sh1), in_relu=1, in_mask=None, in_mask_ld=0, dz=Ref(y512), lddz=512, dw=Ref(torch.zeros(512*CIN, device=dev)), ksplit=0)),
  'wgrad3x3': ('wgrad', dict(n_img=n, H=H, W=W, cin=192, cout=48, taps=9, dil=2, x=Ref(y1), ldx=192, in_scale=Ref(sc2), in_shift=Ref(sh2), in_relu=1, in_mask=None, in_mask_ld=0, dz=Ref(dz48), lddz=48, dw=Ref(dw2), ksplit=0)),
 }
 for cn in (48, 96, 144):      # in-group data gradient: a narrow column range at channel CIN - cn of the slab
