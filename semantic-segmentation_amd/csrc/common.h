@@ -29,6 +29,8 @@ int dsaspp_wgrad_group_launch(const dsaspp_wgrad_desc& d, hipStream_t s);
 
 // 1x1 weight gradient with many input and output channels on a 256 x 256 tile (wgrad_wide.hip): -1 = not of its form, 0 = launched
 int dsaspp_wgrad_wide_launch(const dsaspp_wgrad_desc& d, hipStream_t s);
+// 3x3 weight gradient of a dense layer, every activation row drawn once for all nine taps (wgrad3x3_strip.hip): same return convention
+int dsaspp_wgrad3x3_strip_launch(const dsaspp_wgrad_desc& d, hipStream_t s);
 // records the kernel family of the calling thread's most recent convolution / weight-gradient op (dsaspp_conv_last_route)
 void dsaspp_note_route(const char* name);
 

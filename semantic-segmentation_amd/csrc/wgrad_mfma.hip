@@ -359,6 +359,13 @@ extern "C" int dsaspp_conv_wgrad(const dsaspp_wgrad_desc* dp, dsaspp_stream_t st
             return rc;
         }
     }
+    if (d.taps == 9) {
+        const int rc = dsaspp_wgrad3x3_strip_launch(d, s);  // dense-layer 3x3 (cout 32 / 48, dilation <= 4, 32 | W): column strips, all nine taps per activation row
+        if (rc >= 0) {
+            dsaspp_note_route("wgrad3x3_strip");
+            return rc;
+        }
+    }
     dsaspp_note_route("wgrad_tile");
     const int co = d.cout;
     if (co <= 32) return launch<32, 192, 1, 4>(d, s);

@@ -14,7 +14,7 @@ CLASSES = ['untimed',
            'wgrad_kernel<64,192,1,4>', 'wgrad_kernel<192,128,4,2>', 'wgrad_kernel<128,128,2,4>',
            'upce_kernel<19>', 'wgrad_kernel<48,192,1,4>', 'wgrad_kernel<32,192,1,4>', 'dgrad_group_kernel', 'conv3x3_halo_kernel',
            'conv1x1_stream_kernel<192>', 'conv1x1_stream_kernel<128>', 'wgrad_group_kernel', 'dgrad3x3_fused_kernel', 'dgrad_wide_kernel', 'conv_wide_kernel',
-           'wgrad_wide_kernel']
+           'wgrad_wide_kernel', 'wgrad3x3_strip_kernel']
 
 
 def kernel_class(kind, f):
@@ -62,6 +62,10 @@ def kernel_class(kind, f):
         if (f['taps'] == 1 and f.get('in_mask') is None and f.get('in_relu') in (0, 1, None) and f['cin'] >= 512 and co >= 448
                 and not f.get('dtype') and os.environ.get('DSASPP_WGRAD_WIDE', '1') != '0'):
             return 20
+        if (f['taps'] == 9 and 1 <= f['dil'] <= 4 and f['W'] % 32 == 0 and f['cin'] % 64 == 0 and co in (32, 48)
+                and f.get('in_mask') is None and f.get('in_relu') in (0, 1, None) and not f.get('dtype')
+                and os.environ.get('DSASPP_WGRAD3_STRIP', '1') != '0'):
+            return 21
         if co <= 32:
             return 11
         if co <= 48:

@@ -288,6 +288,27 @@ def test_wgrad_wide(cin, cout, kw):
     assert pkg._lib.conv_last_route() == 'wgrad_wide'
 
 
+@pytest.mark.parametrize('kw,grid', [
+    (dict(n=2, H=20, W=64, cin=192, cout=48, dil=4), 6),              # two blocks per channel range: segments that cross column strips
+    (dict(n=3, H=9, W=96, cin=128, cout=32, dil=1), 4),               # 32 output channels, two channel ranges
+    (dict(n=1, H=33, W=32, cin=64, cout=48, dil=2, scale=False), 1),  # one strip, one block, ReLU only
+    (dict(n=2, H=12, W=64, cin=192, cout=48, dil=1, ldx=208, lddz=56, relu=False), 9),
+    (dict(n=2, H=3, W=32, cin=64, cout=48, dil=4), 2),                # fewer rows than the dilation: only the middle filter row meets data
+    (dict(n=2, H=40, W=128, cin=192, cout=48, dil=2), 0),             # full grid: 170 blocks per channel range, one or two rows each
+    (dict(n=1, H=24, W=256, cin=192, cout=48, dil=4), 24)])
+def test_wgrad3x3_strip(kw, grid, monkeypatch):
+    """3x3 weight gradient of a dense layer by column strips (every activation row staged once for all nine taps, dz rows
+    in a ring): image borders on all four sides, segments that start and end inside a strip, blocks that walk several
+    strips, both output widths."""
+    if grid:
+        monkeypatch.setenv('DSASPP_DGG_GRID', str(grid))
+    f = wgrad_fields(taps=9, seed=700 + kw['H'], **kw)
+    out = run_both('wgrad', f)
+    assert float(out['dw'][0].abs().max()) > 0
+    close(out['dw'][0], out['dw'][1], 5e-3, 'wgrad3x3_strip.dw')
+    assert pkg._lib.conv_last_route() == 'wgrad3x3_strip'
+
+
 @pytest.mark.parametrize('case', range(len(WGRAD_CASES)))
 def test_wgrad(case):
     f = wgrad_fields(seed=case, **WGRAD_CASES[case])

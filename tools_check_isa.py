@@ -11,7 +11,7 @@ import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(ROOT, 'semantic-segmentation_amd', 'csrc')
-DEFAULT = ['dgrad_wide.hip', 'conv_wide.hip', 'wgrad_wide.hip', 'dgrad_group.hip', 'wgrad_group.hip', 'conv1x1_stream.hip', 'dgrad3x3_fused.hip', 'conv3x3_halo.hip']
+DEFAULT = ['dgrad_wide.hip', 'conv_wide.hip', 'wgrad_wide.hip', 'wgrad3x3_strip.hip', 'dgrad_group.hip', 'wgrad_group.hip', 'conv1x1_stream.hip', 'dgrad3x3_fused.hip', 'conv3x3_halo.hip']
 
 
 def demangle(names):
