@@ -752,7 +752,7 @@ class Engine:
                 grp_dy1 = []
                 # the group's bottleneck weight gradients in one launch (the slab prefix is streamed once for all of
                 # them): needs the group's bottleneck gradients side by side, which the grouped data gradient needs too
-                group_wgrad = self.wgrad_group and len(grp) > 1 and not self.side_wgrad and grp[0].mid <= 192
+                group_wgrad = self.wgrad_group and len(grp) > 1 and grp[0].mid <= 192
                 for k, l in enumerate(grp):
                     n1, n2 = l.prefix + '.norm1', l.prefix + '.norm2'
                     y1 = self.y1[l.prefix]
@@ -812,6 +812,8 @@ class Engine:
                         wg.update(zip(names, src))
                     WG(n_img=B, H=H, W=W, cout=grp[0].mid, taps=1, dil=1, x=_r(slab.x), ldx=slab.C, in_relu=1,
                        lddz=grp[0].mid, **wg)
+                    if self.side_wgrad:
+                        ops.mark_side()
                 multi = dict(n_src=len(grp))
                 for k, l in enumerate(grp):
                     n1 = l.prefix + '.norm1'
