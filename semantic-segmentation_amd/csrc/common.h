@@ -17,7 +17,7 @@ int dsaspp_dgrad_group_launch(const dsaspp_conv_desc& d, hipStream_t s);
 // single-source slab data gradient with a long K on a 256 x 256 tile (dgrad_wide.hip): same return convention
 int dsaspp_dgrad_wide_launch(const dsaspp_conv_desc& d, hipStream_t s);
 // BN-ReLU-1x1 forward with many output channels and a long K on the same tile (conv_wide.hip): same return convention
-int dsaspp_conv_wide_launch(const dsaspp_conv_desc& d, hipStream_t s);
+int dsaspp_conv_wide_launch(const dsaspp_conv_desc& d, hipStream_t s, bool narrow_only = false);
 // halo-patch 3x3 convolution with few output channels (conv3x3_halo.hip): same return convention
 int dsaspp_conv3x3_halo_launch(const dsaspp_conv_desc& d, hipStream_t s);
 

@@ -21,16 +21,24 @@
 
 namespace {
 
-constexpr int BP = 256, BQ = 256, BK = 32;
+constexpr int BP = 256, BK = 32;
 constexpr int NW = 8, NT = 512, WP = 2, WQ = 4;
-constexpr int TP = BP / WP, TQ = BQ / WQ, MP = TP / 16, MQ = TQ / 16;    // 128 x 64 wave tile: 8 x 4 MFMA tiles
-constexpr int STAGE = (BP + BQ) * BK * 2;                                 // 32 KiB: pixel half, then filter half
+constexpr int TP = BP / WP, MP = TP / 16;                                 // a wave owns 128 pixels: 8 MFMA tiles
 constexpr int NS = 3;                                                     // ring stages
-constexpr int ROWF = TQ + 4;                                              // patch row in floats (bank spread)
-constexpr int PATCH_BYTES = NW * 16 * ROWF * 4;
-constexpr int SRED_BYTES = WP * 2 * BQ * 4;                               // [pixel half][which sum][channel]
-constexpr int FIXED_LDS = NS * STAGE + PATCH_BYTES + SRED_BYTES;
 constexpr int NGRP = MP, NRP = 4;                                         // 16-pixel groups of the wave tile, 4-pixel passes per group
+// Per output-channel width of the block tile.  256: wave tile 128 x 64 (transitions, ASPP 1x1).  192: wave tile 128 x 48
+// (the dense layers' bottleneck convolution, whose 192 output channels would leave a quarter of the 256-wide tile empty):
+// the filter half of a stage is 12 row groups of 16, so waves 4..7 issue one filter DMA per step instead of two.
+template <int BQ>
+struct Geo {
+    static constexpr int TQ = BQ / WQ, MQ = TQ / 16;
+    static constexpr int STAGE = (BP + BQ) * BK * 2;                      // pixel half, then filter half (32 / 28 KiB)
+    static constexpr int ROWF = TQ + 4;                                   // patch row in floats (bank spread)
+    static constexpr int PATCH_BYTES = NW * 16 * ROWF * 4;
+    static constexpr int SRED_BYTES = WP * 2 * BQ * 4;                    // [pixel half][which sum][channel]
+    static constexpr int FIXED_LDS = NS * STAGE + PATCH_BYTES + SRED_BYTES;
+    static constexpr int NDMA_HI = BQ / 16 - NW;                          // waves below this index issue a second filter DMA
+};
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -56,8 +64,10 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 
 // ODD: the number of K-steps per tile is odd (the steps alternate between two register buffers; a kernel-wide parity
 // keeps the end of a tile straight-line code instead of two paths that meet in front of the epilogue)
-template <bool STATS, bool ODD>
+template <int BQ, bool STATS, bool ODD>
 __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
+    constexpr int TQ = Geo<BQ>::TQ, MQ = Geo<BQ>::MQ, STAGE = Geo<BQ>::STAGE, ROWF = Geo<BQ>::ROWF;
+    constexpr int PATCH_BYTES = Geo<BQ>::PATCH_BYTES, FIXED_LDS = Geo<BQ>::FIXED_LDS, NDMA_HI = Geo<BQ>::NDMA_HI;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;
     float* patch = reinterpret_cast<float*>(smem + NS * STAGE);
@@ -129,8 +139,9 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const uint32_t off = w_off[i] + kbw;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         : : "s"(slot_l + (i * 8 + wave) * 1024), "v"(off), "s"(a.w) : "memory");
+            if (i == 0 || NDMA_HI >= NW || wave < NDMA_HI)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                             : : "s"(slot_l + (i * 8 + wave) * 1024), "v"(off), "s"(a.w) : "memory");
         }
         const uint32_t kbx = (c_kk * BK + xkc * 8 < cin) ? (uint32_t)(c_kk * BK + xkc * 8) * 2u : 0u;
         xo_n[0] = x_off[0] + kbx;
@@ -151,6 +162,17 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
         }
     };
     // pixel chunks of the stage issue_w() was last called for, into one of two register buffers
+    // the one counted wait of a step: everything but this step's own requests has landed (a wave that issues one filter
+    // DMA per step has one request fewer in flight; `last`: the step requested no pixel chunks)
+    auto wait_landed = [&](const bool last) {
+        if (NDMA_HI >= NW || wave < NDMA_HI) {
+            if (last) wait_vm<2>();
+            else wait_vm<4>();
+        } else {
+            if (last) wait_vm<1>();
+            else wait_vm<3>();
+        }
+    };
     auto issue_x = [&](u32x4 (&buf)[2], int& kk_buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(buf[i]) : "v"(xo_n[i]), "s"(a.x) : "memory");
@@ -191,7 +213,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                     // tables visible
     asm volatile("" ::: "memory");
-    wait_vm<4>();
+    wait_landed(false);
     consume(xb, kk_b, 0);
     int r_slot = 0;
 
@@ -236,8 +258,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
             issue_w();
             if (!last) issue_x(next, kk_next);
             mfmas();
-            if (last) wait_vm<2>();
-            else wait_vm<4>();
+            wait_landed(last);
             const int w_slot = r_slot + 1 < NS ? r_slot + 1 : 0;
             consume(landed, kk_landed, w_slot);
             r_slot = w_slot;
@@ -262,9 +283,11 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
         const int er = lane_e >> 4, ec = lane_e & 15;        // row layout: pixel er of a 4-pixel pass, channel quad ec
         const int fr_e = lane_e & 15, g_e = lane_e >> 4;     // accumulator layout
         float* stage = patch + wave * (16 * ROWF);
-        const int qw = q_base + wq * TQ + ec * 4;           // this lane's channel quad (cout is a multiple of 4)
-        const bool qok = qw < cout;
-        const int cl = wq * TQ + ec * 4;
+        const bool qin = ec * 4 < TQ;                       // (a 48-channel wave tile: quads 12..15 of a pass are idle)
+        const int ecc = qin ? ec : 0;
+        const int qw = q_base + wq * TQ + ecc * 4;          // this lane's channel quad (cout is a multiple of 4)
+        const bool qok = qin && qw < cout;
+        const int cl = wq * TQ + ecc * 4;
         const int p_w = p_base + wp * TP + er;
         const uint32_t qoff = (uint32_t)(qok ? qw : 0) * 2u, ldy2 = (uint32_t)a.ldy * 2u;
         unsigned char* yb = reinterpret_cast<unsigned char*>(a.y);
@@ -279,7 +302,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int rp = 0; rp < NRP; ++rp) {
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(stage + (rp * 4 + er) * ROWF + ec * 4);
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(stage + (rp * 4 + er) * ROWF + ecc * 4);
                 int p = p_w + j * 16 + rp * 4;
                 asm volatile("" : "+v"(p));
                 const bool ok = qok && p < M;
@@ -306,15 +329,15 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
                 s2[e] += __shfl_xor(s2[e], 16, 64);
                 s2[e] += __shfl_xor(s2[e], 32, 64);
             }
-            if (er == 0) {
+            if (er == 0 && qin) {
                 *reinterpret_cast<f32x4*>(sred + (wp * 2 + 0) * BQ + cl) = f32x4{s1[0], s1[1], s1[2], s1[3]};
                 *reinterpret_cast<f32x4*>(sred + (wp * 2 + 1) * BQ + cl) = f32x4{s2[0], s2[1], s2[2], s2[3]};
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            const int which = tid / BQ, cc = tid - which * BQ;       // 512 threads = 2 sums x 256 channels
-            if (q_base + cc < cout)
+            const int which = tid / BQ, cc = tid - which * BQ;       // 2 sums x BQ channels on the first 2 * BQ threads
+            if (which < 2 && q_base + cc < cout)
                 atomicAdd(a.stat + (size_t)rep * 2 * cout + which * cout + q_base + cc, sred[which * BQ + cc] + sred[(2 + which) * BQ + cc]);
         }
         // the pixel chunks of the next tile's second stage (requested late: nothing in flight across the epilogue)
@@ -328,19 +351,12 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
 }  // namespace
 
 // Form check + launch.  Returns -1 when the descriptor is not of the form this kernel is for (the caller then uses the
-// generic kernel), 0 on success, a positive error code otherwise.
-int dsaspp_conv_wide_launch(const dsaspp_conv_desc& d, hipStream_t s) {
-    static const int enabled = [] { const char* e = getenv("DSASPP_CONV_WIDE"); return e ? atoi(e) : 1; }();
-    if (!enabled) return -1;
-    const bool form = d.taps == 1 && d.y && !d.y_f32 && !d.g && !d.epi_relu && !d.s_acc && ((d.in_scale != nullptr) == (d.in_shift != nullptr)) && !d.in_mask &&
-                      (d.in_relu == 0 || d.in_relu == 1) && !d.out_mask && d.n_src <= 1 && d.dtype == 0 && !d.gx_corr1 && d.cin % 8 == 0 &&
-                      d.ldx % 8 == 0 && d.cout % 4 == 0 && d.ldy % 4 == 0;
-    if (!form) return -1;
-    static const int min_cin = [] { const char* e = getenv("DSASPP_CONV_WIDE_MIN_CIN"); return e ? atoi(e) : 512; }();
-    static const int min_cout = [] { const char* e = getenv("DSASPP_CONV_WIDE_MIN_COUT"); return e ? atoi(e) : 448; }();
-    if (d.cin < min_cin || d.cout < min_cout) return -1;
+// generic kernel), 0 on success, a positive error code otherwise.  129..192 output channels take the 192-wide tile
+// (`narrow_only`: the caller asks for that form alone, in front of the streaming kernel).
+template <int BQ>
+static int conv_wide_launch_t(const dsaspp_conv_desc& d, hipStream_t s) {
     const int cinp = (d.cin + BK - 1) / BK * BK;
-    const size_t lds = (size_t)FIXED_LDS + (size_t)cinp * 8;
+    const size_t lds = (size_t)Geo<BQ>::FIXED_LDS + (size_t)cinp * 8;
     if (lds > 160 * 1024) return -1;
     const int64_t M64 = (int64_t)d.n_img * d.H * d.W;
     // operand and output offsets are 32-bit byte offsets from the tensor base
@@ -367,8 +383,8 @@ int dsaspp_conv_wide_launch(const dsaspp_conv_desc& d, hipStream_t s) {
     if (n_cu == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-        const void* kernels[] = {(const void*)conv_wide_kernel<true, true>, (const void*)conv_wide_kernel<true, false>, (const void*)conv_wide_kernel<false, true>,
-                                 (const void*)conv_wide_kernel<false, false>};
+        const void* kernels[] = {(const void*)conv_wide_kernel<BQ, true, true>, (const void*)conv_wide_kernel<BQ, true, false>,
+                                 (const void*)conv_wide_kernel<BQ, false, true>, (const void*)conv_wide_kernel<BQ, false, false>};
         for (const void* f : kernels) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     const int64_t tiles = (int64_t)a.nP * a.nQ;
@@ -381,9 +397,30 @@ int dsaspp_conv_wide_launch(const dsaspp_conv_desc& d, hipStream_t s) {
     if (grid > cap) grid = cap;
     if (grid < 8) grid = 8;
     const bool odd = ((cinp / BK) & 1) != 0;
-    void (*kern)(const CWArgs) = d.stat_acc ? (odd ? conv_wide_kernel<true, true> : conv_wide_kernel<true, false>)
-                                            : (odd ? conv_wide_kernel<false, true> : conv_wide_kernel<false, false>);
+    void (*kern)(const CWArgs) = d.stat_acc ? (odd ? conv_wide_kernel<BQ, true, true> : conv_wide_kernel<BQ, true, false>)
+                                            : (odd ? conv_wide_kernel<BQ, false, true> : conv_wide_kernel<BQ, false, false>);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, a);
     DS_LAUNCH_CHECK("conv_fwd(wide forward 1x1)");
     return 0;
+}
+
+int dsaspp_conv_wide_launch(const dsaspp_conv_desc& d, hipStream_t s, bool narrow_only) {
+    static const int enabled = [] { const char* e = getenv("DSASPP_CONV_WIDE"); return e ? atoi(e) : 1; }();
+    if (!enabled) return -1;
+    const bool form = d.taps == 1 && d.y && !d.y_f32 && !d.g && !d.epi_relu && !d.s_acc && ((d.in_scale != nullptr) == (d.in_shift != nullptr)) && !d.in_mask &&
+                      (d.in_relu == 0 || d.in_relu == 1) && !d.out_mask && d.n_src <= 1 && d.dtype == 0 && !d.gx_corr1 && d.cin % 8 == 0 &&
+                      d.ldx % 8 == 0 && d.cout % 4 == 0 && d.ldy % 4 == 0;
+    if (!form) return -1;
+    // the dense layers' bottleneck convolution (DSASPP_CONV_WIDE192=0: left to the streaming kernel)
+    static const int en192 = [] { const char* e = getenv("DSASPP_CONV_WIDE192"); return e ? atoi(e) : 1; }();
+    // (measured at 16 x 128 x 256 pixels against the streaming kernel: 90 vs 128 us at cin 96, 229 vs 256 at 480, 466 vs 474
+    // at 1248, 546 vs 540 at 1488, 707 vs 686 at 2064: the long-K layers stay with the streaming kernel)
+    static const int min_cin192 = [] { const char* e = getenv("DSASPP_CONV_WIDE192_MIN_CIN"); return e ? atoi(e) : 64; }();
+    static const int max_cin192 = [] { const char* e = getenv("DSASPP_CONV_WIDE192_MAX_CIN"); return e ? atoi(e) : 1392; }();
+    if (en192 && d.cout > 128 && d.cout <= 192 && d.cin >= min_cin192 && d.cin <= max_cin192) return conv_wide_launch_t<192>(d, s);
+    if (narrow_only) return -1;
+    static const int min_cin = [] { const char* e = getenv("DSASPP_CONV_WIDE_MIN_CIN"); return e ? atoi(e) : 512; }();
+    static const int min_cout = [] { const char* e = getenv("DSASPP_CONV_WIDE_MIN_COUT"); return e ? atoi(e) : 448; }();
+    if (d.cin < min_cin || d.cout < min_cout) return -1;
+    return conv_wide_launch_t<256>(d, s);
 }

@@ -70,7 +70,7 @@ def check_conv(f, tol=2e-2):
 CONV_CASES = [
     # BN-ReLU-1x1 forward with cout <= 192 (streaming form): slab-strided input, K tail, row tail, two output widths,
     # output into a channel slice, with and without statistics
-    dict(n=2, H=23, W=31, cin=1248, cout=192, taps=1, dil=1, ldx=1296, stats=True),
+    dict(n=2, H=23, W=31, cin=1488, cout=192, taps=1, dil=1, ldx=1520, stats=True),
     dict(n=1, H=17, W=19, cin=200, cout=128, taps=1, dil=1, ldx=208, ldy=160, yoff=16, stats=True),
     dict(n=3, H=16, W=16, cin=64, cout=96, taps=1, dil=1),
     dict(n=1, H=40, W=52, cin=392, cout=184, taps=1, dil=1, xoff=8, stats=True),
@@ -186,6 +186,26 @@ def test_conv_wide(cin, cout, kw, monkeypatch):
         monkeypatch.setenv('DSASPP_DGG_GRID', str(grid))
     check_conv(conv_fields(n=3, H=24, W=33, cin=cin, cout=cout, taps=1, dil=1, seed=300 + cin, **kw))
     assert pkg._lib.conv_last_route() == 'conv_wide'
+
+
+@pytest.mark.parametrize('cin,cout,kw', [
+    (1248, 192, dict(stats=True, ldx=1296, grid=8)),              # 39 K-steps (odd), several pixel tiles per block
+    (1280, 160, dict(ldy=200, yoff=8, grid=16)),                  # 40 K-steps (even), channel tail, strided output, no statistics
+    (264, 184, dict(stats=True, xoff=8)),                         # K tail of 8 channels, one tile per block, blocks without a tile
+    (1392, 136, dict(stats=True, bias=True, grid=8)),             # longest K routed here, a channel count that ends inside a wave tile
+    (512, 192, dict(stats=True, scale=False)),                    # ReLU -> conv (table of ones and zeros)
+    (64, 192, dict(stats=True, grid=8)),                          # two K-steps per tile: the ring wraps inside every tile
+    (96, 176, dict(stats=True, ldx=144, grid=8)),                 # three
+    (72, 192, dict(stats=True))])                                 # K tail of 8 channels in the third step
+def test_conv_wide192(cin, cout, kw, monkeypatch):
+    """BN-ReLU-1x1 forward with 129..192 output channels on the 256 x 192 tile (the dense layers' bottleneck convolution):
+    waves 4..7 issue one filter DMA per step and wait with their own count; 48-channel wave tiles in the epilogue."""
+    kw = dict(kw)
+    grid = kw.pop('grid', 0)
+    if grid:
+        monkeypatch.setenv('DSASPP_DGG_GRID', str(grid))
+    check_conv(conv_fields(n=3, H=24, W=33, cin=cin, cout=cout, taps=1, dil=1, seed=500 + cin, **kw))
+    assert pkg._lib.conv_last_route() == 'conv_wide192'
 
 
 def test_conv_s_slice():
