@@ -19,6 +19,11 @@
 
 #include "common.h"
 
+// -DCW_ABL_X=1: diagnostic build in which every block reads the same 1024 pixel rows (cache-resident pixel operand)
+#ifndef CW_ABL_X
+#define CW_ABL_X 0
+#endif
+
 namespace {
 
 constexpr int BP = 256, BK = 32;
@@ -124,6 +129,9 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
             w_off[i] = (uint32_t)q * (uint32_t)cin * 2u;
             int p = pb + xrow + i * 128;
             p = p < M ? p : M - 1;
+#if CW_ABL_X
+            p &= 1023;                                 // diagnostic build: every block reads the same cache-resident rows
+#endif
             x_off[i] = (uint32_t)p * (uint32_t)a.ldx * 2u;
         }
     };
