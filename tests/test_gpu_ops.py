@@ -473,6 +473,11 @@ def test_stem_ops():
              col=Ref(torch.ones(n * (H // 2) * (W // 2) * 160, dtype=torch.bfloat16)), ldcol=160)
     out = run_both('im2col', f)
     assert torch.equal(out['col'][0].float(), out['col'][1].float())
+    # an output row of three 64-pixel segments, the last one partial; a wider column pitch
+    f2 = dict(n_img=3, H=10, W=300, x=Ref(torch.randn(3 * 3 * 10 * 300, generator=gen)),
+              col=Ref(torch.ones(3 * 5 * 150 * 168, dtype=torch.bfloat16)), ldcol=168)
+    out = run_both('im2col', f2)
+    assert torch.equal(out['col'][0].float(), out['col'][1].float())
     Hc, Wc = H // 2, W // 2
     Mi, Mo = n * Hc * Wc, n * (Hc // 2) * (Wc // 2)
     x = bf(torch.randn(Mi * C, generator=gen))
