@@ -754,8 +754,8 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
         }
     }
     if (d.taps == 1) {   // BN-ReLU-1x1 forward with few output channels: streaming kernel (DSASPP_STREAM1X1=0 disables it)
-        if (d.cout > 128 && d.cout <= 192) {         // ... 129..192 of them and a long enough K: 256 x 192 tile
-            conv_route = "conv_wide192";
+        if (d.cout > 64 && d.cout <= 192) {          // ... 65..192 of them and a K in the range where it wins: 256 x 192 / 256 x 128 tile
+            conv_route = "conv_wide_narrow";
             const int rcn = dsaspp_conv_wide_launch(d, s, true);
             if (rcn >= 0) return rcn;
         }

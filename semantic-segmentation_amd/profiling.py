@@ -14,7 +14,7 @@ CLASSES = ['untimed',
            'wgrad_kernel<64,192,1,4>', 'wgrad_kernel<192,128,4,2>', 'wgrad_kernel<128,128,2,4>',
            'upce_kernel<19>', 'wgrad_kernel<48,192,1,4>', 'wgrad_kernel<32,192,1,4>', 'dgrad_group_kernel', 'conv3x3_halo_kernel',
            'conv1x1_stream_kernel<192>', 'conv1x1_stream_kernel<128>', 'wgrad_group_kernel', 'dgrad3x3_fused_kernel', 'dgrad_wide_kernel', 'conv_wide_kernel<256>',
-           'wgrad_wide_kernel', 'wgrad3x3_strip_kernel', 'conv_wide_kernel<192>']
+           'wgrad_wide_kernel', 'wgrad3x3_strip_kernel', 'conv_wide_kernel<192>', 'conv_wide_kernel<128>']
 
 
 def kernel_class(kind, f):
@@ -37,12 +37,17 @@ def kernel_class(kind, f):
                 and not f.get('epi_relu') and f.get('s_acc') is None and not f.get('y_f32') and f.get('in_mask') is None
                 and f.get('bias') is None and f.get('out_mask') is None):
             return 13
-        if (f['taps'] == 1 and 128 < co <= 192 and f.get('in_relu') in (0, 1, None) and f.get('in_mask') is None
+        if (f['taps'] == 1 and 64 < co <= 192 and f.get('in_relu') in (0, 1, None) and f.get('in_mask') is None
                 and f.get('out_mask') is None and not f.get('y_f32') and not f.get('epi_relu') and f.get('s_acc') is None
                 and f.get('g') is None and co % 4 == 0 and not f.get('dtype') and (f.get('n_src') or 0) <= 1
-                and int(os.environ.get('DSASPP_CONV_WIDE192_MIN_CIN', 64)) <= f['cin'] <= int(os.environ.get('DSASPP_CONV_WIDE192_MAX_CIN', 1392))
-                and os.environ.get('DSASPP_CONV_WIDE', '1') != '0' and os.environ.get('DSASPP_CONV_WIDE192', '1') != '0'):
-            return 22                          # BN-ReLU-1x1 forward on the 256 x 192 tile (conv_wide.hip)
+                and os.environ.get('DSASPP_CONV_WIDE', '1') != '0'):
+            # BN-ReLU-1x1 forward on the 256 x 192 / 256 x 128 tile (conv_wide.hip), in the K range where it is used
+            env = os.environ.get
+            if (co > 128 and int(env('DSASPP_CONV_WIDE192_MIN_CIN', 64)) <= f['cin'] <= int(env('DSASPP_CONV_WIDE192_MAX_CIN', 1392))
+                    and env('DSASPP_CONV_WIDE192', '1') != '0'):
+                return 22
+            if co <= 128 and 64 <= f['cin'] <= int(env('DSASPP_CONV_WIDE128_MAX_CIN', 512)) and env('DSASPP_CONV_WIDE128', '1') != '0':
+                return 23
         if (f['taps'] == 1 and 96 <= co <= 192 and f.get('in_scale') is not None and f.get('in_relu') == 1
                 and f.get('in_mask') is None and f.get('bias') is None and f.get('out_mask') is None and not f.get('y_f32')
                 and not f.get('epi_relu') and f.get('s_acc') is None and f.get('g') is None and f['cin'] >= 64

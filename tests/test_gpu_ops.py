@@ -71,8 +71,8 @@ CONV_CASES = [
     # BN-ReLU-1x1 forward with cout <= 192 (streaming form): slab-strided input, K tail, row tail, two output widths,
     # output into a channel slice, with and without statistics
     dict(n=2, H=23, W=31, cin=1488, cout=192, taps=1, dil=1, ldx=1520, stats=True),
-    dict(n=1, H=17, W=19, cin=200, cout=128, taps=1, dil=1, ldx=208, ldy=160, yoff=16, stats=True),
-    dict(n=3, H=16, W=16, cin=64, cout=96, taps=1, dil=1),
+    dict(n=1, H=17, W=19, cin=600, cout=128, taps=1, dil=1, ldx=608, ldy=160, yoff=16, stats=True),
+    dict(n=3, H=16, W=16, cin=576, cout=96, taps=1, dil=1),
     dict(n=1, H=40, W=52, cin=392, cout=184, taps=1, dil=1, xoff=8, stats=True),
     # merged-K form (3x3, raw input with fewer channels than one K-step): K = 9*cin laid end to end
     dict(n=2, H=11, W=9, cin=32, cout=128, taps=9, dil=2, scale=False, relu=False, epi_relu=True, e_scale=True, s_acc=True),
@@ -196,16 +196,22 @@ def test_conv_wide(cin, cout, kw, monkeypatch):
     (512, 192, dict(stats=True, scale=False)),                    # ReLU -> conv (table of ones and zeros)
     (64, 192, dict(stats=True, grid=8)),                          # two K-steps per tile: the ring wraps inside every tile
     (96, 176, dict(stats=True, ldx=144, grid=8)),                 # three
-    (72, 192, dict(stats=True))])                                 # K tail of 8 channels in the third step
-def test_conv_wide192(cin, cout, kw, monkeypatch):
-    """BN-ReLU-1x1 forward with 129..192 output channels on the 256 x 192 tile (the dense layers' bottleneck convolution):
-    waves 4..7 issue one filter DMA per step and wait with their own count; 48-channel wave tiles in the epilogue."""
+    (72, 192, dict(stats=True)),                                  # K tail of 8 channels in the third step
+    # 65..128 output channels on the 256 x 128 tile (every wave issues one filter DMA per step; 32-channel wave tiles)
+    (128, 128, dict(stats=True, grid=8)),
+    (200, 128, dict(stats=True, ldx=208, ldy=160, yoff=16)),
+    (512, 96, dict(stats=True, bias=True, grid=16)),
+    (64, 72, dict(stats=True))])
+def test_conv_wide_narrow(cin, cout, kw, monkeypatch):
+    """BN-ReLU-1x1 forward with 65..192 output channels on the 256 x 192 / 256 x 128 tile (the dense layers' bottleneck
+    convolution): waves 4..7 issue one filter DMA per step and wait with their own count; 48- and 32-channel wave tiles in
+    the epilogue."""
     kw = dict(kw)
     grid = kw.pop('grid', 0)
     if grid:
         monkeypatch.setenv('DSASPP_DGG_GRID', str(grid))
     check_conv(conv_fields(n=3, H=24, W=33, cin=cin, cout=cout, taps=1, dil=1, seed=500 + cin, **kw))
-    assert pkg._lib.conv_last_route() == 'conv_wide192'
+    assert pkg._lib.conv_last_route() == 'conv_wide_narrow'
 
 
 def test_conv_s_slice():

@@ -8,7 +8,7 @@ from semantic_segmentation_amd.backend import HipBackend
 from semantic_segmentation_amd.engine import Ref
 ap = argparse.ArgumentParser(); ap.add_argument('--batch', type=int, default=4); ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--only', default=''); ap.add_argument('--cin', type=int, default=1248)
-ap.add_argument('--tile', default=''); a = ap.parse_args()
+ap.add_argument('--tile', default=''); ap.add_argument('--cout', type=int, default=192); a = ap.parse_args()
 if a.tile: os.environ['DSASPP_CONV_TILE'] = a.tile
 dev = 'cuda'; be = HipBackend(); R = 16
 n, H, W = a.batch, 128, 256; M = n*H*W; LD = 2112; CIN = a.cin
@@ -36,7 +36,7 @@ base = dict(in_scale=None, in_shift=None, in_relu=0, in_mask=None, in_mask_ld=0,
 def conv(**kw):
     d = dict(base); d.update(kw); return ('conv', d)
 cases = {
- 'fwd1x1': conv(n_img=n, H=H, W=W, cin=CIN, cout=192, taps=1, dil=1, x=Ref(slab), ldx=LD, w=Ref(w1), in_scale=Ref(sc1), in_shift=Ref(sh1), in_relu=1, y=Ref(y1), ldy=192, stat_acc=Ref(acc)),
+ 'fwd1x1': conv(n_img=n, H=H, W=W, cin=CIN, cout=a.cout, taps=1, dil=1, x=Ref(slab), ldx=LD, w=Ref(w1), in_scale=Ref(sc1), in_shift=Ref(sh1), in_relu=1, y=Ref(y1), ldy=a.cout, stat_acc=Ref(acc)),
  'fwd3x3': conv(n_img=n, H=H, W=W, cin=192, cout=48, taps=9, dil=2, x=Ref(y1), ldx=192, w=Ref(w2), in_scale=Ref(sc2), in_shift=Ref(sh2), in_relu=1, y=Ref(slab, CIN), ldy=LD, stat_acc=Ref(acc)),
  'fwd3x3_d4': conv(n_img=n, H=H, W=W, cin=192, cout=48, taps=9, dil=4, x=Ref(y1), ldx=192, w=Ref(w2), in_scale=Ref(sc2), in_shift=Ref(sh2), in_relu=1, y=Ref(slab, CIN), ldy=LD, stat_acc=Ref(acc)),
  'dgrad3x3': conv(n_img=n, H=H, W=W, cin=48, cout=192, taps=9, dil=2, x=Ref(dz48), ldx=48, w=Ref(w2t), y=Ref(dr), ldy=192, y_f32=1, epi_relu=1, ref=Ref(y1), ldref=192, e_scale=Ref(sc2), e_shift=Ref(sh2), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc)),
