@@ -366,6 +366,13 @@ extern "C" int dsaspp_conv_wgrad(const dsaspp_wgrad_desc* dp, dsaspp_stream_t st
             return rc;
         }
     }
+    if (d.taps == 9) {
+        const int rc = dsaspp_wgrad_wide_launch(d, s);      // many input channels (ASPP 3x3): 256 x 256 tile over nine shifted copies of dz
+        if (rc >= 0) {
+            dsaspp_note_route("wgrad_wide9");
+            return rc;
+        }
+    }
     dsaspp_note_route("wgrad_tile");
     const int co = d.cout;
     if (co <= 32) return launch<32, 192, 1, 4>(d, s);

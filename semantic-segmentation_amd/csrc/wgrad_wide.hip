@@ -16,6 +16,17 @@
 // where it pleases) and after the MFMAs of step t writes the chunks of step t + 1 into that stage's slot.
 // Queue per wave and step: [2 dz DMAs][2 x chunk loads]; one counted wait, vmcnt(4), in front of the prologue work.
 // Pixel rows past the end contribute zero through the x side (their dz rows are fetched from the last valid row).
+//
+// T9: the dilated 3x3 form with many input channels (the ASPP 3x3 layers, 512 -> 128, dilation 3 .. 24),
+//
+//   dw[q][ky][kx][c] += sum_{n,h,w} dz[n][h - (ky-1)*dil][w - (kx-1)*dil][q] * A[n][h][w][c]        (dz = 0 outside the image)
+//
+// as the same GEMM over a VIRTUAL dz operand of 9 * cout channels: virtual channel t * cout + q of pixel row p is channel q
+// of the dz row shifted by tap t.  Only the source address of the dz DMA changes: every lane owns one 16-byte chunk
+// position of a stage row, i.e. a fixed (tap, channel) pair, follows the (h, w) coordinates of its row from step to step
+// (rows advance by 32 pixels: at most one wrap when W >= 32) and fetches from the shifted row, or -- outside the image,
+// past the last virtual channel or past the last pixel -- from a row of zeros; the address is a 64-bit per-lane one for
+// that reason.  The x side and the K-loop are those of the 1x1 form; 256 virtual channels are two taps of 128.
 #include <stdlib.h>
 
 #include "common.h"
@@ -42,9 +53,15 @@ struct WWArgs {
     const float* sc;
     const float* sh;
     float* dw;
-    int ldx, lddz, cin, cout, M, nQ, nC, chunk;
+    int ldx, lddz, cin, cout, M, nQ, nC, chunk;      // cout: channels of the (virtual) dz operand
     uint32_t relu_bits;
+    // 3x3 form
+    const unsigned char* zero;                       // >= 16 bytes of zeros
+    int H, W, dil, qreal;                            // qreal: output channels of the layer (cout = 9 * qreal)
 };
+
+// zeros for the dz DMA of the 3x3 form (a static device array is zero-initialised; one copy per GPU)
+__device__ __attribute__((aligned(256))) unsigned int g_zero_row[64];
 
 // block swizzle of a stage row: rows r..r+3 of one transposed read differ in the low two bits, the two lane groups that
 // are served together (rows r and r + 8) in the third
@@ -61,6 +78,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint32_t addr) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+template <bool T9>
 __global__ __launch_bounds__(NT, 2) void wgrad_wide_kernel(const WWArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* ring = smem;
@@ -80,6 +98,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_wide_kernel(const WWArgs a) {
     const int m_last = a.M - 1 - m_begin;             // last valid row, relative to the range (>= 0)
     // operand bases of this block as scalars; per-lane parts are 32-bit byte offsets
     const unsigned char* zbase = reinterpret_cast<const unsigned char*>(a.dz + (int64_t)m_begin * a.lddz + q_base);
+    const unsigned char* zimg = reinterpret_cast<const unsigned char*>(a.dz);
     const unsigned char* xbase = reinterpret_cast<const unsigned char*>(a.x + (int64_t)m_begin * a.ldx + c_base);
     const uint32_t lddz2 = (uint32_t)a.lddz * 2u, ldx2 = (uint32_t)a.ldx * 2u;
     const uint32_t ring_l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)ring);
@@ -104,12 +123,29 @@ __global__ __launch_bounds__(NT, 2) void wgrad_wide_kernel(const WWArgs a) {
     //      the chunk that belongs at its lane-linear position
     int zrow[2];
     uint32_t zc_off[2];
+    // 3x3 form: this lane's tap offsets, whether its virtual channel exists, and the image coordinates of its row at the
+    // stage that is requested next
+    int zdy[2], zdx[2], zh[2], zw[2];
+    bool zvc[2];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         zrow[n] = wave * 4 + n * 2 + (lane >> 5);
         const int p = lane & 31;
         const int gc = (((p >> 1) ^ swz(zrow[n])) << 1) | (p & 1);
-        zc_off[n] = (q_base + gc * 8 < cout) ? (uint32_t)gc * 16u : 0u;
+        if (T9) {
+            const int Qc = q_base + gc * 8;
+            zvc[n] = Qc < cout;
+            const int t = zvc[n] ? Qc / a.qreal : 0;
+            const int ky = t / 3, kx = t - ky * 3;
+            zdy[n] = (ky - 1) * a.dil;
+            zdx[n] = (kx - 1) * a.dil;
+            zc_off[n] = (uint32_t)(Qc - t * a.qreal) * 2u;
+            const int p0 = (m_begin + zrow[n]) % (a.H * a.W);
+            zh[n] = p0 / a.W;
+            zw[n] = p0 - zh[n] * a.W;
+        } else {
+            zc_off[n] = (q_base + gc * 8 < cout) ? (uint32_t)gc * 16u : 0u;
+        }
     }
 
     int c_slot = 0;
@@ -117,11 +153,26 @@ __global__ __launch_bounds__(NT, 2) void wgrad_wide_kernel(const WWArgs a) {
         const uint32_t slot_l = ring_l + c_slot * STAGE;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            int rel = s * BK + zrow[n];
-            rel = rel < m_last ? rel : m_last;
-            const uint32_t off = (uint32_t)rel * lddz2 + zc_off[n];
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         : : "s"(slot_l + (wave * 2 + n) * 1024), "v"(off), "s"(zbase) : "memory");
+            if (T9) {
+                // (stages are requested in order, so the coordinates advance by one stage per call)
+                const int rel = s * BK + zrow[n];
+                const int hs = zh[n] - zdy[n], ws = zw[n] - zdx[n];
+                const bool ok = zvc[n] && rel <= m_last && (unsigned)hs < (unsigned)a.H && (unsigned)ws < (unsigned)a.W;
+                const unsigned char* src = ok ? zimg + ((int64_t)(m_begin + rel) - (int64_t)zdy[n] * a.W - zdx[n]) * (int64_t)lddz2 + zc_off[n] : a.zero;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                             : : "s"(slot_l + (wave * 2 + n) * 1024), "v"(src) : "memory");
+                zw[n] += BK;
+                if (zw[n] >= a.W) {
+                    zw[n] -= a.W;
+                    zh[n] = zh[n] + 1 < a.H ? zh[n] + 1 : 0;
+                }
+            } else {
+                int rel = s * BK + zrow[n];
+                rel = rel < m_last ? rel : m_last;
+                const uint32_t off = (uint32_t)rel * lddz2 + zc_off[n];
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                             : : "s"(slot_l + (wave * 2 + n) * 1024), "v"(off), "s"(zbase) : "memory");
+            }
         }
         c_slot = c_slot + 1 < NS ? c_slot + 1 : 0;
     };
@@ -224,7 +275,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad_wide_kernel(const WWArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = q_base + wq * TQ + i * 16 + fc * 4 + r;
-                if (q < cout) atomicAdd(a.dw + (int64_t)q * cin + c, acc[i][j][r]);
+                if (q >= cout) continue;
+                if (T9) {       // virtual channel t * qreal + qq -> dw[qq][t][c]
+                    const int t = q / a.qreal, qq = q - t * a.qreal;
+                    atomicAdd(a.dw + ((int64_t)qq * 9 + t) * cin + c, acc[i][j][r]);
+                } else {
+                    atomicAdd(a.dw + (int64_t)q * cin + c, acc[i][j][r]);
+                }
             }
         }
     }
@@ -237,12 +294,15 @@ __global__ __launch_bounds__(NT, 2) void wgrad_wide_kernel(const WWArgs a) {
 int dsaspp_wgrad_wide_launch(const dsaspp_wgrad_desc& d, hipStream_t s) {
     static const int enabled = [] { const char* e = getenv("DSASPP_WGRAD_WIDE"); return e ? atoi(e) : 1; }();
     if (!enabled) return -1;
-    const bool form = d.taps == 1 && d.n_src <= 1 && d.dtype == 0 && !d.in_mask && (d.in_relu == 0 || d.in_relu == 1) &&
+    const bool t9 = d.taps == 9;
+    const bool form = (d.taps == 1 || (t9 && d.W >= BK && d.dil >= 1)) && d.n_src <= 1 && d.dtype == 0 && !d.in_mask && (d.in_relu == 0 || d.in_relu == 1) &&
                       ((d.in_scale != nullptr) == (d.in_shift != nullptr)) && d.cin % 8 == 0 && d.cout % 8 == 0 && d.ldx % 8 == 0 && d.lddz % 8 == 0;
     if (!form) return -1;
     static const int min_cin = [] { const char* e = getenv("DSASPP_WGRAD_WIDE_MIN_CIN"); return e ? atoi(e) : 512; }();
     static const int min_cout = [] { const char* e = getenv("DSASPP_WGRAD_WIDE_MIN_COUT"); return e ? atoi(e) : 448; }();
-    if (d.cin < min_cin || d.cout < min_cout) return -1;
+    const int cout_v = t9 ? 9 * d.cout : d.cout;     // channels of the (virtual) dz operand
+    if (d.cin < min_cin || cout_v < min_cout) return -1;
+    if (t9 && (int64_t)d.dil * (d.W + 1) >= (1ll << 30)) return -1;
     const int64_t M64 = (int64_t)d.n_img * d.H * d.W;
     if (M64 >= (1ll << 31)) return -1;
     if ((((uintptr_t)d.x | (uintptr_t)d.dz) & 15) != 0 || (d.in_scale && ((((uintptr_t)d.in_scale | (uintptr_t)d.in_shift) & 15) != 0))) return -1;
@@ -250,11 +310,25 @@ int dsaspp_wgrad_wide_launch(const dsaspp_wgrad_desc& d, hipStream_t s) {
     if (n_cu == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-        (void)hipFuncSetAttribute((const void*)wgrad_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    // the row of zeros of the 3x3 form: one copy per GPU, its address looked up once per device and thread
+    static thread_local int zero_dev = -1;
+    static thread_local const unsigned char* zero_ptr = nullptr;
+    if (t9) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return -1;
+        if (dev != zero_dev) {
+            void* zp = nullptr;
+            if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_row)) != hipSuccess || !zp) return -1;
+            zero_ptr = static_cast<const unsigned char*>(zp);
+            zero_dev = dev;
+        }
     }
     WWArgs a;
     a.M = (int)M64;
-    a.nQ = (d.cout + BQ - 1) / BQ;
+    a.nQ = (cout_v + BQ - 1) / BQ;
     a.nC = (d.cin + BC - 1) / BC;
     const int tiles = a.nQ * a.nC;
     // one round of resident blocks (one per CU): the fewest atomic epilogues
@@ -275,10 +349,16 @@ int dsaspp_wgrad_wide_launch(const dsaspp_wgrad_desc& d, hipStream_t s) {
     a.ldx = d.ldx;
     a.lddz = d.lddz;
     a.cin = d.cin;
-    a.cout = d.cout;
+    a.cout = cout_v;
     a.chunk = (int)chunk;
+    a.zero = zero_ptr;
+    a.H = d.H;
+    a.W = d.W;
+    a.dil = d.dil;
+    a.qreal = d.cout;
     a.relu_bits = d.in_relu ? 0u : 0x80008000u;
-    hipLaunchKernelGGL(wgrad_wide_kernel, dim3(tiles * ksplit), dim3(NT), (size_t)NS * STAGE, s, a);
-    DS_LAUNCH_CHECK("conv_wgrad(wide 1x1)");
+    if (t9) hipLaunchKernelGGL(wgrad_wide_kernel<true>, dim3(tiles * ksplit), dim3(NT), (size_t)NS * STAGE, s, a);
+    else hipLaunchKernelGGL(wgrad_wide_kernel<false>, dim3(tiles * ksplit), dim3(NT), (size_t)NS * STAGE, s, a);
+    DS_LAUNCH_CHECK("conv_wgrad(wide tile)");
     return 0;
 }

@@ -77,6 +77,9 @@ def kernel_class(kind, f):
                 and f.get('in_mask') is None and f.get('in_relu') in (0, 1, None) and not f.get('dtype')
                 and os.environ.get('DSASPP_WGRAD3_STRIP', '1') != '0'):
             return 21
+        if (f['taps'] == 9 and f['W'] >= 32 and f.get('in_mask') is None and f.get('in_relu') in (0, 1, None) and f['cin'] >= 512
+                and 9 * co >= 448 and not f.get('dtype') and os.environ.get('DSASPP_WGRAD_WIDE', '1') != '0'):
+            return 20                          # dilated 3x3 with many input channels (ASPP): the wide tile over nine shifted copies of dz
         if co <= 32:
             return 11
         if co <= 48:

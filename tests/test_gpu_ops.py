@@ -314,6 +314,22 @@ def test_wgrad_wide(cin, cout, kw):
     assert pkg._lib.conv_last_route() == 'wgrad_wide'
 
 
+@pytest.mark.parametrize('H,W,cin,cout,dil,kw', [
+    (24, 33, 512, 128, 3, dict()),                         # the ASPP shape: nine taps = 4.5 tiles of 256 virtual channels; rows wrap every step
+    (16, 40, 520, 128, 6, dict(ldx=544, lddz=136)),        # input-channel tail of 8, strided operands
+    (12, 64, 512, 56, 12, dict(ksplit=1, relu=False)),     # dilation beyond the image height: only the centre row of taps sees data; 504 virtual channels
+    (40, 32, 768, 128, 24, dict(scale=False, ksplit=5)),   # W = one stage of pixels, dilation 24
+    (9, 50, 512, 72, 1, dict())])                          # taps straddle the 256-channel tiles (72 does not divide 256)
+def test_wgrad_wide_3x3(H, W, cin, cout, dil, kw):
+    """Dilated 3x3 weight gradient with many input channels (the ASPP 3x3 layers) on the 256 x 256 tile: the dz operand is
+    nine shifted copies of dz side by side, fetched by per-lane 64-bit DMA addresses with a row of zeros outside the image."""
+    f = wgrad_fields(n=3, H=H, W=W, cin=cin, cout=cout, taps=9, dil=dil, seed=700 + cin + dil, **kw)
+    out = run_both('wgrad', f)
+    assert float(out['dw'][0].abs().max()) > 0
+    close(out['dw'][0], out['dw'][1], 5e-3, 'wgrad_wide9.dw')
+    assert pkg._lib.conv_last_route() == 'wgrad_wide9'
+
+
 @pytest.mark.parametrize('kw,grid', [
     (dict(n=2, H=20, W=64, cin=192, cout=48, dil=4), 6),              # two blocks per channel range: segments that cross column strips
     (dict(n=3, H=9, W=96, cin=128, cout=32, dil=1), 4),               # 32 output channels, two channel ranges
