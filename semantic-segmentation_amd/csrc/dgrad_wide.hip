@@ -17,6 +17,15 @@
 //     loaded one group ahead, the product is masked, summed, scaled and stored.
 // The K-loop's DMAs are issued from inline assembly and waited for by a counted s_waitcnt; everything else is left to
 // the compiler, whose own wait counts do not know about the DMAs in the queue and therefore only wait longer.
+//
+// T9: the dilated 3x3 data gradient with many output channels (the ASPP 3x3 layers, 128 -> 512, dilation 3 .. 24),
+//
+//   y[p][c] = [ref[p][c] * e_scale[c] + e_shift[c] > 0] * sum_t x[p + off_t][:] . w[c][t][:]        (x = 0 outside the image)
+//
+// as the same GEMM with K = 9 * cin: a K-step of 32 channels lies inside one tap (32 | cin), so the step's tap offset is
+// a scalar, and only the source address of the pixel rows changes -- a lane fetches its row shifted by the tap, or, where
+// that falls outside the image, a row of zeros (64-bit per-lane address).  The product is stored unscaled and
+// overwrites y (the form the generic kernel writes for this layer).
 #include <stdlib.h>
 
 #include "common.h"
@@ -50,8 +59,14 @@ struct WArgs {
     float* sa;
     const u16* ref;
     u16* g;
-    int ldx, ldref, ldg, cin, cout, sld, M, nP, nQ, accumulate;
+    int ldx, ldref, ldg, cin, cout, sld, M, nP, nQ, accumulate;      // cin: K of the GEMM (9 * cin_real in the 3x3 form)
+    // 3x3 form
+    const unsigned char* zero;                       // >= 16 bytes of zeros
+    int H, W, dil, cin_real;
 };
+
+// zeros for the pixel-row DMA of the 3x3 form (a static device array is zero-initialised; one copy per GPU)
+__device__ __attribute__((aligned(256))) unsigned int g_zero_row_dw[64];
 
 // chunk swizzle of a 64-byte stage row: position of K chunk c in row r is c ^ swz(r).  With it the sixteen lanes of every
 // ds_read_b128 lane group (eight fragment rows at chunk c, the other eight rows of the 16-row tile at chunk c + 1) fall
@@ -61,7 +76,7 @@ __device__ __forceinline__ int swz(int row) { return (0 - (row >> 2)) & 3; }
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
-template <bool ACCG>
+template <bool ACCG, bool T9>
 __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;
@@ -93,6 +108,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
     const uint32_t ring_l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)ring);
     int c_k = 0, c_kk = 0, c_slot = 0;
     uint32_t r_off[4];                                // byte offset of this lane's row in its tensor
+    int ph[2], pw[2], pflat[2];                       // 3x3 form: image coordinates and flat index of this lane's two pixel rows (-1: past the end)
     const int lrow = lane >> 2;
     auto cursor_tile = [&]() {
         int pb, qb;
@@ -102,6 +118,12 @@ __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
             const int row = ((i & 1) * 8 + wave) * 16 + lrow;      // row inside the pixel half (i < 2) or the filter half of the stage
             if (i < 2) {
                 int p = pb + row;
+                if (T9) {
+                    pflat[i] = p < M ? p : -1;
+                    const int rem = (p < M ? p : 0) % (a.H * a.W);
+                    ph[i] = rem / a.W;
+                    pw[i] = rem - ph[i] * a.W;
+                }
                 p = p < M ? p : M - 1;
                 r_off[i] = (uint32_t)p * (uint32_t)a.ldx * 2u;
             } else {
@@ -117,8 +139,26 @@ __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
         // a chunk past the last channel: fetch the row's first chunk instead (finite values of the same tensor); the step's
         // MFMAs see zeros in the pixel operand there
         const uint32_t kb = (c_kk * BK + lchunk * 8 < cin) ? (uint32_t)(c_kk * BK + lchunk * 8) * 2u : 0u;
+        // 3x3 form: the step's tap (a K-step lies inside one tap) and this lane's channel inside it
+        int dy = 0, dx = 0;
+        uint32_t kx_b = 0;
+        if (T9) {
+            const int t = (c_kk * BK) / a.cin_real;
+            const int ky = t / 3;
+            dy = (ky - 1) * a.dil;
+            dx = (t - ky * 3 - 1) * a.dil;
+            kx_b = (uint32_t)(c_kk * BK - t * a.cin_real + lchunk * 8) * 2u;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if (T9 && i < 2) {
+                const bool ok = pflat[i] >= 0 && (unsigned)(ph[i] + dy) < (unsigned)a.H && (unsigned)(pw[i] + dx) < (unsigned)a.W;
+                const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(a.x) + ((int64_t)pflat[i] + (int64_t)dy * a.W + dx) * ((int64_t)a.ldx * 2) + kx_b
+                                              : a.zero;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                             : : "s"(slot_l + (i * 8 + wave) * 1024), "v"(src) : "memory");
+                continue;
+            }
             const uint32_t off = r_off[i] + kb;
             const u16* base = i < 2 ? a.x : a.w;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
@@ -270,7 +310,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
                     const float v = (ok && pre > 0.f) ? a4[e] : 0.f;     // rows past M were computed from a repeated row
                     s1[e] += v;
                     s2[e] = fmaf(v, rf[e], s2[e]);
-                    t[e] = v * es[e];
+                    t[e] = T9 ? v : v * es[e];
                 }
                 // (the sums pass through an empty asm statement: the store below sits in a branch, and the compiler otherwise
                 // sinks the 256 additions of the tile below the last branch, with their operands kept alive until then)
@@ -325,19 +365,38 @@ __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
 int dsaspp_dgrad_wide_launch(const dsaspp_conv_desc& d, hipStream_t s) {
     static const int enabled = [] { const char* e = getenv("DSASPP_DGRAD_WIDE"); return e ? atoi(e) : 1; }();
     if (!enabled) return -1;
-    const bool form = d.g && d.g_bf16 && d.taps == 1 && d.epi_relu == 1 && d.ref && d.e_scale && d.e_shift && d.e_mean && d.e_rstd && !d.in_scale &&
-                      !d.in_mask && !d.in_relu && !d.bias && !d.out_mask && d.n_src <= 1 && d.dtype == 0 && d.cin % 8 == 0 && d.ldx % 8 == 0 &&
-                      d.cout % 4 == 0 && d.ldref % 4 == 0 && d.ldg % 4 == 0;
-    if (!form) return -1;
+    const bool common = d.epi_relu == 1 && d.ref && d.e_scale && d.e_shift && d.e_mean && d.e_rstd && !d.in_scale && !d.in_mask && !d.in_relu && !d.bias &&
+                        !d.out_mask && d.n_src <= 1 && d.dtype == 0 && d.cin % 8 == 0 && d.ldx % 8 == 0 && d.cout % 4 == 0 && d.ldref % 4 == 0 && !d.gx_corr1;
+    const bool form1 = common && d.g && d.g_bf16 && d.taps == 1 && d.ldg % 4 == 0;
+    // the 3x3 form writes y (bf16, unscaled, overwritten): the ASPP 3x3 data gradient
+    const bool t9 = common && !d.g && d.y && !d.y_f32 && d.taps == 9 && d.cin % BK == 0 && d.ldy % 4 == 0 && d.dil >= 1 && !d.stat_acc;
+    if (!form1 && !t9) return -1;
     static const int min_cin = [] { const char* e = getenv("DSASPP_DGRAD_WIDE_MIN_CIN"); return e ? atoi(e) : 256; }();
     static const int min_cout = [] { const char* e = getenv("DSASPP_DGRAD_WIDE_MIN_COUT"); return e ? atoi(e) : 512; }();
-    if (d.cin < min_cin || d.cout < min_cout) return -1;
+    const int kdim = t9 ? 9 * d.cin : d.cin;
+    if (kdim < min_cin || d.cout < min_cout) return -1;
     const int64_t M64 = (int64_t)d.n_img * d.H * d.W;
+    void* outp = t9 ? d.y : d.g;
+    const int ldo = t9 ? d.ldy : d.ldg;
     // operand offsets are 32-bit byte offsets from the tensor base
-    if (M64 * d.ldx * 2 >= (1ll << 32) || (int64_t)d.cout * d.cin * 2 >= (1ll << 32) || M64 >= (1ll << 31) || M64 * d.ldref * 2 >= (1ll << 32) ||
-        M64 * d.ldg * 2 >= (1ll << 32))
+    if (M64 * d.ldx * 2 >= (1ll << 32) || (int64_t)d.cout * kdim * 2 >= (1ll << 32) || M64 >= (1ll << 31) || M64 * d.ldref * 2 >= (1ll << 32) ||
+        M64 * ldo * 2 >= (1ll << 32))
         return -1;
-    if ((((uintptr_t)d.ref | (uintptr_t)d.g) & 7) != 0) return -1;
+    if ((((uintptr_t)d.ref | (uintptr_t)outp) & 7) != 0) return -1;
+    if (t9 && (int64_t)d.dil * (d.W + 1) >= (1ll << 30)) return -1;
+    // the row of zeros of the 3x3 form: one copy per GPU, its address looked up once per device and thread
+    static thread_local int zero_dev = -1;
+    static thread_local const unsigned char* zero_ptr = nullptr;
+    if (t9) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return -1;
+        if (dev != zero_dev) {
+            void* zp = nullptr;
+            if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_row_dw)) != hipSuccess || !zp) return -1;
+            zero_ptr = static_cast<const unsigned char*>(zp);
+            zero_dev = dev;
+        }
+    }
     WArgs a;
     a.x = reinterpret_cast<const u16*>(d.x);
     a.w = reinterpret_cast<const u16*>(d.w);
@@ -347,23 +406,29 @@ int dsaspp_dgrad_wide_launch(const dsaspp_conv_desc& d, hipStream_t s) {
     a.rstd = d.e_rstd;
     a.sa = d.s_acc;
     a.ref = reinterpret_cast<const u16*>(d.ref);
-    a.g = reinterpret_cast<u16*>(d.g);
+    a.g = reinterpret_cast<u16*>(outp);
     a.ldx = d.ldx;
     a.ldref = d.ldref;
-    a.ldg = d.ldg;
-    a.cin = d.cin;
+    a.ldg = ldo;
+    a.cin = kdim;
+    a.zero = zero_ptr;
+    a.H = d.H;
+    a.W = d.W;
+    a.dil = d.dil;
+    a.cin_real = d.cin;
     a.cout = d.cout;
     a.sld = d.s_ld > 0 ? d.s_ld : d.cout;
     a.M = (int)M64;
     a.nP = (a.M + BP - 1) / BP;
     a.nQ = (d.cout + BQ - 1) / BQ;
-    a.accumulate = d.g_accumulate;
+    a.accumulate = t9 ? 0 : d.g_accumulate;
     static thread_local int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     }
     const int64_t tiles = (int64_t)a.nP * a.nQ;
     int grid = (int)((tiles + 7) / 8 * 8);
@@ -374,8 +439,9 @@ int dsaspp_dgrad_wide_launch(const dsaspp_conv_desc& d, hipStream_t s) {
     }
     if (grid > cap) grid = cap;
     if (grid < 8) grid = 8;
-    if (d.g_accumulate) hipLaunchKernelGGL(dgrad_wide_kernel<true>, dim3(grid), dim3(NT), LDS_BYTES, s, a);
-    else hipLaunchKernelGGL(dgrad_wide_kernel<false>, dim3(grid), dim3(NT), LDS_BYTES, s, a);
+    if (t9) hipLaunchKernelGGL((dgrad_wide_kernel<false, true>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
+    else if (d.g_accumulate) hipLaunchKernelGGL((dgrad_wide_kernel<true, false>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((dgrad_wide_kernel<false, false>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
     DS_LAUNCH_CHECK("conv_fwd(wide data gradient)");
     return 0;
 }

@@ -27,6 +27,11 @@ def kernel_class(kind, f):
                 and f.get('in_mask') is None and not f.get('in_relu') and f.get('bias') is None and f.get('out_mask') is None
                 and not f.get('dtype') and f['cin'] >= 256 and co >= 512 and co % 4 == 0 and os.environ.get('DSASPP_DGRAD_WIDE', '1') != '0'):
             return 18
+        if (f['taps'] == 9 and f.get('g') is None and f.get('epi_relu') == 1 and co >= 512 and co % 4 == 0 and f['cin'] % 32 == 0 and 9 * f['cin'] >= 256
+                and f.get('ref') is not None and f.get('e_scale') is not None and f.get('e_mean') is not None and f.get('in_scale') is None
+                and f.get('in_mask') is None and not f.get('in_relu') and f.get('bias') is None and f.get('out_mask') is None
+                and not f.get('dtype') and not f.get('y_f32') and f.get('stat_acc') is None and os.environ.get('DSASPP_DGRAD_WIDE', '1') != '0'):
+            return 18                          # dilated 3x3 data gradient with many output channels (ASPP) on the wide tile
         if (f.get('n_src') or 0) > 1 or (
                 f.get('g') is not None and co >= int(os.environ.get('DSASPP_DGG_MIN_COUT', 48)) and f['taps'] == 1 and f.get('epi_relu') and f.get('ref') is not None
                 and f.get('e_scale') is not None and f.get('e_mean') is not None and f.get('in_scale') is None

@@ -170,6 +170,25 @@ def test_dgrad_wide(cin, cout, g_acc, stats, grid, monkeypatch):
     assert pkg._lib.conv_last_route() == 'dgrad_wide'
 
 
+@pytest.mark.parametrize('H,W,cin,cout,dil,kw', [
+    (24, 33, 128, 512, 3, dict(s_acc=True, grid=8)),              # the ASPP shape: 36 K-steps, four per tap; several tiles per block
+    (16, 40, 128, 520, 6, dict(s_acc=True, ldx=136, ldy=544, yoff=8)),       # channel tail of 8, strided operands
+    (12, 64, 64, 512, 12, dict(s_acc=True)),                      # dilation beyond the image height; two K-steps per tap
+    (40, 20, 32, 776, 24, dict(s_acc=True, grid=16)),             # one K-step per tap, dilation beyond the width
+    (9, 50, 96, 512, 1, dict(s_acc=True))])
+def test_dgrad_wide_3x3(H, W, cin, cout, dil, kw, monkeypatch):
+    """Dilated 3x3 data gradient with many output channels (the ASPP 3x3 layers) on the 256 x 256 tile: K = 9 * cin, the
+    pixel rows of a K-step fetched shifted by the step's tap through per-lane 64-bit DMA addresses, zeros outside the image;
+    masked by the reference tensor, BatchNorm-backward sums, output stored unscaled."""
+    kw = dict(kw)
+    grid = kw.pop('grid', 0)
+    if grid:
+        monkeypatch.setenv('DSASPP_DGG_GRID', str(grid))
+    check_conv(conv_fields(n=3, H=H, W=W, cin=cin, cout=cout, taps=9, dil=dil, scale=False, relu=False, epi_relu=True, e_scale=True,
+                           seed=900 + cout + dil, **kw))
+    assert pkg._lib.conv_last_route() == 'dgrad_wide9'
+
+
 @pytest.mark.parametrize('cin,cout,kw', [
     (1104, 512, dict(stats=True, grid=8)),                        # K tail of 16 channels, two full channel tiles
     (520, 456, dict(stats=True, ldx=544, ldy=520, yoff=8)),       # K tail of 8, partial channel tile, strided in and out
