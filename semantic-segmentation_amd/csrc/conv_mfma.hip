@@ -745,7 +745,7 @@ extern "C" int dsaspp_conv_fwd(const dsaspp_conv_desc* dp, dsaspp_stream_t strea
         const int rc = dsaspp_dgrad_group_launch(d, s);
         if (rc >= 0) return rc;
     }
-    if (d.taps == 9 && !d.g && d.epi_relu == 1 && d.cout >= 512) {      // 3x3 data gradient with many output channels (ASPP): 256 x 256 tile
+    if (d.taps == 9 && !d.g && d.epi_relu == 1 && d.cout >= 448) {      // 3x3 data gradient with many output channels (ASPP): 256 x 256 tile
         const int rc = dsaspp_dgrad_wide_launch(d, s);
         if (rc >= 0) {
             conv_route = "dgrad_wide9";

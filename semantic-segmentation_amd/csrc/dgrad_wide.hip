@@ -22,8 +22,8 @@
 //
 //   y[p][c] = [ref[p][c] * e_scale[c] + e_shift[c] > 0] * sum_t x[p + off_t][:] . w[c][t][:]        (x = 0 outside the image)
 //
-// as the same GEMM with K = 9 * cin: a K-step of 32 channels lies inside one tap (32 | cin), so the step's tap offset is
-// a scalar, and only the source address of the pixel rows changes -- a lane fetches its row shifted by the tap, or, where
+// as the same GEMM with K = 9 * cin (taps side by side, the order the transposed filter is stored in): only the source
+// address of the pixel rows changes -- a lane fetches its row shifted by the tap its 8-channel chunk belongs to, or, where
 // that falls outside the image, a row of zeros (64-bit per-lane address).  The product is stored unscaled and
 // overwrites y (the form the generic kernel writes for this layer).
 #include <stdlib.h>
@@ -76,7 +76,8 @@ __device__ __forceinline__ int swz(int row) { return (0 - (row >> 2)) & 3; }
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
-template <bool ACCG, bool T9>
+// T9: 0 = 1x1 form; 1 = 3x3 form with 32 | cin (a K-step lies inside one tap: the tap is a scalar); 2 = 3x3 form, any cin >= 32
+template <bool ACCG, int T9>
 __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
     const uint32_t ring_l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)ring);
     int c_k = 0, c_kk = 0, c_slot = 0;
     uint32_t r_off[4];                                // byte offset of this lane's row in its tensor
-    int ph[2], pw[2], pflat[2];                       // 3x3 form: image coordinates and flat index of this lane's two pixel rows (-1: past the end)
+    int phw[2];                                       // 3x3 form: image coordinates (h << 16 | w) of this lane's two pixel rows; rows past the end: far outside
     const int lrow = lane >> 2;
     auto cursor_tile = [&]() {
         int pb, qb;
@@ -119,10 +120,9 @@ __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
             if (i < 2) {
                 int p = pb + row;
                 if (T9) {
-                    pflat[i] = p < M ? p : -1;
                     const int rem = (p < M ? p : 0) % (a.H * a.W);
-                    ph[i] = rem / a.W;
-                    pw[i] = rem - ph[i] * a.W;
+                    const int h = rem / a.W;
+                    phw[i] = p < M ? (h << 16) | (rem - h * a.W) : 0x7fff7fff;
                 }
                 p = p < M ? p : M - 1;
                 r_off[i] = (uint32_t)p * (uint32_t)a.ldx * 2u;
@@ -139,22 +139,32 @@ __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
         // a chunk past the last channel: fetch the row's first chunk instead (finite values of the same tensor); the step's
         // MFMAs see zeros in the pixel operand there
         const uint32_t kb = (c_kk * BK + lchunk * 8 < cin) ? (uint32_t)(c_kk * BK + lchunk * 8) * 2u : 0u;
-        // 3x3 form: the step's tap (a K-step lies inside one tap) and this lane's channel inside it
+        // 3x3 form: the tap of this lane's chunk and its channel inside the tap.  A K-step of 32 channels meets at most two
+        // taps (cin >= 32): the step's first tap is a scalar, a chunk past its end belongs to the next one; a chunk past
+        // the last tap (K tail of the last step) reads zeros
         int dy = 0, dx = 0;
         uint32_t kx_b = 0;
+        bool tap_ok = true;
         if (T9) {
-            const int t = (c_kk * BK) / a.cin_real;
+            const int t0 = (c_kk * BK) / a.cin_real;
+            int kin = c_kk * BK - t0 * a.cin_real + lchunk * 8;
+            int t = t0;
+            if (T9 == 2 && kin >= a.cin_real) {
+                kin -= a.cin_real;
+                ++t;
+            }
+            tap_ok = t < 9;
             const int ky = t / 3;
             dy = (ky - 1) * a.dil;
             dx = (t - ky * 3 - 1) * a.dil;
-            kx_b = (uint32_t)(c_kk * BK - t * a.cin_real + lchunk * 8) * 2u;
+            kx_b = (uint32_t)kin * 2u;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (T9 && i < 2) {
-                const bool ok = pflat[i] >= 0 && (unsigned)(ph[i] + dy) < (unsigned)a.H && (unsigned)(pw[i] + dx) < (unsigned)a.W;
-                const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(a.x) + ((int64_t)pflat[i] + (int64_t)dy * a.W + dx) * ((int64_t)a.ldx * 2) + kx_b
-                                              : a.zero;
+                const bool ok = tap_ok && (unsigned)((phw[i] >> 16) + dy) < (unsigned)a.H && (unsigned)((phw[i] & 0xffff) + dx) < (unsigned)a.W;
+                // (the row's own byte offset is the one of the 1x1 form; the tap's shift in bytes fits 32 bits: launcher)
+                const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(a.x) + r_off[i] + (int64_t)((dy * a.W + dx) * (a.ldx * 2)) + kx_b : a.zero;
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                              : : "s"(slot_l + (i * 8 + wave) * 1024), "v"(src) : "memory");
                 continue;
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
         // groups requested before the last K-step / in flight at most.  Accumulating (two loads per pass), three groups are
         // what fits beside the accumulators without a spill; with five, 17 registers went to scratch, every reload was
         // waited for with vmcnt(0) -- which also waits for the whole prefetch -- and the launches took 6-8 % longer
-        constexpr int EARLY = 2, AHEAD = ACCG ? 3 : NGRP;
+        constexpr int EARLY = 2, AHEAD = ACCG ? 3 : (T9 ? 6 : NGRP);      // (3x3 form: the lane's row coordinates live across the tile; all 8 groups in flight spilled 3 registers)
         u32x2 rfv[NGRP][NRP], gov[ACCG ? NGRP : 1][NRP];
         auto load_group = [&](const int j) {
             int pj = p_w + j * 16;
@@ -369,12 +379,12 @@ int dsaspp_dgrad_wide_launch(const dsaspp_conv_desc& d, hipStream_t s) {
                         !d.out_mask && d.n_src <= 1 && d.dtype == 0 && d.cin % 8 == 0 && d.ldx % 8 == 0 && d.cout % 4 == 0 && d.ldref % 4 == 0 && !d.gx_corr1;
     const bool form1 = common && d.g && d.g_bf16 && d.taps == 1 && d.ldg % 4 == 0;
     // the 3x3 form writes y (bf16, unscaled, overwritten): the ASPP 3x3 data gradient
-    const bool t9 = common && !d.g && d.y && !d.y_f32 && d.taps == 9 && d.cin % BK == 0 && d.ldy % 4 == 0 && d.dil >= 1 && !d.stat_acc;
+    const bool t9 = common && !d.g && d.y && !d.y_f32 && d.taps == 9 && d.cin >= BK && d.ldy % 4 == 0 && d.dil >= 1 && !d.stat_acc;
     if (!form1 && !t9) return -1;
     static const int min_cin = [] { const char* e = getenv("DSASPP_DGRAD_WIDE_MIN_CIN"); return e ? atoi(e) : 256; }();
     static const int min_cout = [] { const char* e = getenv("DSASPP_DGRAD_WIDE_MIN_COUT"); return e ? atoi(e) : 512; }();
     const int kdim = t9 ? 9 * d.cin : d.cin;
-    if (kdim < min_cin || d.cout < min_cout) return -1;
+    if (kdim < min_cin || d.cout < (t9 ? 448 : min_cout)) return -1;
     const int64_t M64 = (int64_t)d.n_img * d.H * d.W;
     void* outp = t9 ? d.y : d.g;
     const int ldo = t9 ? d.ldy : d.ldg;
@@ -383,7 +393,7 @@ int dsaspp_dgrad_wide_launch(const dsaspp_conv_desc& d, hipStream_t s) {
         M64 * ldo * 2 >= (1ll << 32))
         return -1;
     if ((((uintptr_t)d.ref | (uintptr_t)outp) & 7) != 0) return -1;
-    if (t9 && (int64_t)d.dil * (d.W + 1) >= (1ll << 30)) return -1;
+    if (t9 && ((int64_t)d.dil * (d.W + 1) * d.ldx * 2 >= (1ll << 31) || d.H + d.dil >= 32000 || d.W + d.dil >= 32000)) return -1;
     // the row of zeros of the 3x3 form: one copy per GPU, its address looked up once per device and thread
     static thread_local int zero_dev = -1;
     static thread_local const unsigned char* zero_ptr = nullptr;
@@ -426,9 +436,10 @@ int dsaspp_dgrad_wide_launch(const dsaspp_conv_desc& d, hipStream_t s) {
     if (n_cu == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     }
     const int64_t tiles = (int64_t)a.nP * a.nQ;
     int grid = (int)((tiles + 7) / 8 * 8);
@@ -439,9 +450,10 @@ int dsaspp_dgrad_wide_launch(const dsaspp_conv_desc& d, hipStream_t s) {
     }
     if (grid > cap) grid = cap;
     if (grid < 8) grid = 8;
-    if (t9) hipLaunchKernelGGL((dgrad_wide_kernel<false, true>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
-    else if (d.g_accumulate) hipLaunchKernelGGL((dgrad_wide_kernel<true, false>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
-    else hipLaunchKernelGGL((dgrad_wide_kernel<false, false>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
+    if (t9 && d.cin % BK == 0) hipLaunchKernelGGL((dgrad_wide_kernel<false, 1>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
+    else if (t9) hipLaunchKernelGGL((dgrad_wide_kernel<false, 2>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
+    else if (d.g_accumulate) hipLaunchKernelGGL((dgrad_wide_kernel<true, 0>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((dgrad_wide_kernel<false, 0>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
     DS_LAUNCH_CHECK("conv_fwd(wide data gradient)");
     return 0;
 }

@@ -301,7 +301,7 @@ int dsaspp_wgrad_wide_launch(const dsaspp_wgrad_desc& d, hipStream_t s) {
     static const int min_cin = [] { const char* e = getenv("DSASPP_WGRAD_WIDE_MIN_CIN"); return e ? atoi(e) : 512; }();
     static const int min_cout = [] { const char* e = getenv("DSASPP_WGRAD_WIDE_MIN_COUT"); return e ? atoi(e) : 448; }();
     const int cout_v = t9 ? 9 * d.cout : d.cout;     // channels of the (virtual) dz operand
-    if (d.cin < min_cin || cout_v < min_cout) return -1;
+    if (d.cin < (t9 ? 448 : min_cin) || cout_v < min_cout) return -1;
     if (t9 && (int64_t)d.dil * (d.W + 1) >= (1ll << 30)) return -1;
     const int64_t M64 = (int64_t)d.n_img * d.H * d.W;
     if (M64 >= (1ll << 31)) return -1;

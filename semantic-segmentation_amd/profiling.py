@@ -27,7 +27,7 @@ def kernel_class(kind, f):
                 and f.get('in_mask') is None and not f.get('in_relu') and f.get('bias') is None and f.get('out_mask') is None
                 and not f.get('dtype') and f['cin'] >= 256 and co >= 512 and co % 4 == 0 and os.environ.get('DSASPP_DGRAD_WIDE', '1') != '0'):
             return 18
-        if (f['taps'] == 9 and f.get('g') is None and f.get('epi_relu') == 1 and co >= 512 and co % 4 == 0 and f['cin'] % 32 == 0 and 9 * f['cin'] >= 256
+        if (f['taps'] == 9 and f.get('g') is None and f.get('epi_relu') == 1 and co >= 448 and co % 4 == 0 and f['cin'] >= 32 and 9 * f['cin'] >= 256
                 and f.get('ref') is not None and f.get('e_scale') is not None and f.get('e_mean') is not None and f.get('in_scale') is None
                 and f.get('in_mask') is None and not f.get('in_relu') and f.get('bias') is None and f.get('out_mask') is None
                 and not f.get('dtype') and not f.get('y_f32') and f.get('stat_acc') is None and os.environ.get('DSASPP_DGRAD_WIDE', '1') != '0'):
@@ -82,7 +82,7 @@ def kernel_class(kind, f):
                 and f.get('in_mask') is None and f.get('in_relu') in (0, 1, None) and not f.get('dtype')
                 and os.environ.get('DSASPP_WGRAD3_STRIP', '1') != '0'):
             return 21
-        if (f['taps'] == 9 and f['W'] >= 32 and f.get('in_mask') is None and f.get('in_relu') in (0, 1, None) and f['cin'] >= 512
+        if (f['taps'] == 9 and f['W'] >= 32 and f.get('in_mask') is None and f.get('in_relu') in (0, 1, None) and f['cin'] >= 448
                 and 9 * co >= 448 and not f.get('dtype') and os.environ.get('DSASPP_WGRAD_WIDE', '1') != '0'):
             return 20                          # dilated 3x3 with many input channels (ASPP): the wide tile over nine shifted copies of dz
         if co <= 32:

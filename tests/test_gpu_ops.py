@@ -175,7 +175,9 @@ def test_dgrad_wide(cin, cout, g_acc, stats, grid, monkeypatch):
     (16, 40, 128, 520, 6, dict(s_acc=True, ldx=136, ldy=544, yoff=8)),       # channel tail of 8, strided operands
     (12, 64, 64, 512, 12, dict(s_acc=True)),                      # dilation beyond the image height; two K-steps per tap
     (40, 20, 32, 776, 24, dict(s_acc=True, grid=16)),             # one K-step per tap, dilation beyond the width
-    (9, 50, 96, 512, 1, dict(s_acc=True))])
+    (9, 50, 96, 512, 1, dict(s_acc=True)),
+    (20, 36, 240, 480, 6, dict(s_acc=True, grid=8)),              # taps that end inside a K-step (240 = 7.5 steps), K tail of 16 channels
+    (14, 33, 40, 456, 2, dict(s_acc=True))])                      # two taps in most steps
 def test_dgrad_wide_3x3(H, W, cin, cout, dil, kw, monkeypatch):
     """Dilated 3x3 data gradient with many output channels (the ASPP 3x3 layers) on the 256 x 256 tile: K = 9 * cin, the
     pixel rows of a K-step fetched shifted by the step's tap through per-lane 64-bit DMA addresses, zeros outside the image;
@@ -338,7 +340,8 @@ def test_wgrad_wide(cin, cout, kw):
     (16, 40, 520, 128, 6, dict(ldx=544, lddz=136)),        # input-channel tail of 8, strided operands
     (12, 64, 512, 56, 12, dict(ksplit=1, relu=False)),     # dilation beyond the image height: only the centre row of taps sees data; 504 virtual channels
     (40, 32, 768, 128, 24, dict(scale=False, ksplit=5)),   # W = one stage of pixels, dilation 24
-    (9, 50, 512, 72, 1, dict())])                          # taps straddle the 256-channel tiles (72 does not divide 256)
+    (9, 50, 512, 72, 1, dict()),                           # taps straddle the 256-channel tiles (72 does not divide 256)
+    (20, 36, 480, 240, 6, dict())])                        # the ASPP shape of the growth-32 trunk with the widest head
 def test_wgrad_wide_3x3(H, W, cin, cout, dil, kw):
     """Dilated 3x3 weight gradient with many input channels (the ASPP 3x3 layers) on the 256 x 256 tile: the dz operand is
     nine shifted copies of dz side by side, fetched by per-lane 64-bit DMA addresses with a row of zeros outside the image."""
