@@ -18,7 +18,7 @@ def test_cfg_values_match_reference_snapshot():
         assert got == want, name
 
 
-def test_macs_and_params_match_survey_figures():
+def test_macs_and_params_match_hand_computed_figures():
     from cfgs import DenseASPP121, DenseASPP161, DenseASPP169, DenseASPP201
     assert abs(conv_macs(DenseASPP161.Model_CFG, 1024, 2048) / 1e9 - 1239.5) < 0.1
     assert abs(conv_macs(DenseASPP121.Model_CFG, 512, 1024) / 1e9 - 77.2) < 0.1
