@@ -75,6 +75,9 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
     ap.add_argument('--force-reducer', action='store_true',
                     help='one rank, but run the bucketed all-reduce path of N > 1 (rehearsal)')
+    ap.add_argument('--comm-cus', type=int, default=None,
+                    help='compute units the persistent kernels leave free while gradient buckets are in flight (default: '
+                         'distributed.DEFAULT_COMM_CUS when collectives are issued)')
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=2048)
     ap.add_argument('--model', default='DenseASPP161')
@@ -122,7 +125,7 @@ def main():
     gen = torch.Generator(device=device)
     gen.manual_seed(99 + rank)
     eng = model.engine(B, H, W, True)
-    reducer = GradReducer(model, eng, always=args.force_reducer) if (world > 1 or args.force_reducer) else None
+    reducer = GradReducer(model, eng, always=args.force_reducer, comm_cus=args.comm_cus) if (world > 1 or args.force_reducer) else None
     model.refresh_weights()
 
     def step():

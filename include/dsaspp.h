@@ -120,6 +120,14 @@ int dsaspp_conv_fwd(const dsaspp_conv_desc* d, dsaspp_stream_t stream);
  * diagnostic, so that a test of one kernel can tell that its case did not quietly take another route. */
 const char* dsaspp_conv_last_route(void);
 
+/* Compute units to leave free for a collective that runs beside the backward pass.  The bucketed gradient all-reduce
+ * (the reference's implicit nn.DataParallel reduce-add, graph_seg_main.py:173-174,239) is launched while later buckets are
+ * still being computed; the slab data-gradient, wide forward and weight-gradient kernels are persistent, one block per
+ * compute unit, and would otherwise leave the collective's kernels nowhere to run until they finish.  n in [0, 128]
+ * (0 = use every compute unit; the default).  Process-wide; read at every launch.  dsaspp_get_comm_cus returns it. */
+int dsaspp_set_comm_cus(int32_t n);
+int dsaspp_get_comm_cus(void);
+
 /* ------------------------------------------------------------------------------------
  * Weight gradient of the same convolution: dw[cout][taps][cin] (fp32) += sum over pixels
  * of dz[m][cout] * A[m + tap offset][cin], with A = prologue(x) recomputed on the fly

@@ -163,6 +163,9 @@ def load():
                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
     lib.dsaspp_copy2d_f32_bf16.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                            ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    lib.dsaspp_set_comm_cus.argtypes = [ctypes.c_int32]
+    lib.dsaspp_set_comm_cus.restype = ctypes.c_int
+    lib.dsaspp_get_comm_cus.restype = ctypes.c_int
     lib.dsaspp_memset_async.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]
     lib.dsaspp_program_create.restype = ctypes.c_void_p
     lib.dsaspp_program_destroy.argtypes = [ctypes.c_void_p]
@@ -181,6 +184,17 @@ def load():
 def source_hash():
     """Hash of the sources the loaded library was built from (dsaspp_source_hash)."""
     return load().dsaspp_source_hash().decode()
+
+
+def set_comm_cus(n):
+    """Compute units the persistent kernels leave free for a concurrent collective (dsaspp_set_comm_cus)."""
+    lib = load()
+    if lib.dsaspp_set_comm_cus(int(n)) != 0:
+        raise RuntimeError(lib.dsaspp_last_error().decode())
+
+
+def get_comm_cus():
+    return int(load().dsaspp_get_comm_cus())
 
 
 def conv_last_route():

@@ -18,11 +18,17 @@ def _hipcc():
     return 'hipcc'
 
 
-def source_hash():
-    """sha256 over every file the library is compiled from (kernel sources, shared header, public header), in a fixed
-    order: what dsaspp_source_hash() of a library built from this tree returns."""
+# compile flags of the product build: part of the source hash, so that a change here rebuilds the library
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+
+
+def source_hash(extra_flags=()):
+    """sha256 over every file the library is compiled from (kernel sources, shared header, public header) and the
+    compile flags, in a fixed order: what dsaspp_source_hash() of a library built from this tree returns.  A build with
+    extra flags (diagnostic -D switches) has another hash than the product build of the same sources."""
     import hashlib
     h = hashlib.sha256()
+    h.update(' '.join(FLAGS + list(extra_flags)).encode())
     for path in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'common.h'), os.path.join(INCLUDE, 'dsaspp.h')]:
         h.update(os.path.basename(path).encode())
         h.update(open(path, 'rb').read())
@@ -38,20 +44,26 @@ def library_hash():
     return m.group(1).decode() if m else None
 
 
-def build_library(force=False, verbose=False, extra_flags=()):
+def build_library(force=False, verbose=False, extra_flags=(), out=None):
+    """Build the library.  With extra_flags (diagnostic builds, results possibly wrong on purpose) an explicit output
+    path is required: the in-tree product library is only ever written by a build with the product flags."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    sh = source_hash()
-    # rebuilt whenever the sources differ from what the library was built from (not by modification time: a
+    extra_flags = tuple(extra_flags)
+    if extra_flags and out is None:
+        raise ValueError('a build with extra flags %r needs an explicit output path (out=...); it must not replace %s'
+                         % (extra_flags, LIB))
+    lib = out or LIB
+    sh = source_hash(extra_flags)
+    # rebuilt whenever the sources or flags differ from what the library was built from (not by modification time: a
     # checkout or a copy changes times, and a stale prebuilt library would go unnoticed)
-    if not force and library_hash() == sh and not extra_flags:
+    if not force and out is None and library_hash() == sh:
         return LIB
     objs = []
     procs = []
     for src in srcs:
-        obj = src[:-4] + '.o'
+        obj = src[:-4] + ('.o' if out is None else '.%s.o' % sh)
         objs.append(obj)
-        cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', INCLUDE, '-I', CSRC,
-               '-Wall', '-Wno-unused-function', *extra_flags, '-c', src, '-o', obj]
+        cmd = [_hipcc(), *FLAGS, '-I', INCLUDE, '-I', CSRC, *extra_flags, '-c', src, '-o', obj]
         if src.endswith('program.hip'):
             cmd.insert(-4, '-DDSASPP_SOURCE_HASH="%s"' % sh)
         if verbose:
@@ -67,9 +79,12 @@ def build_library(force=False, verbose=False, extra_flags=()):
             print('FAILED: %s' % src, file=sys.stderr)
     if failed:
         raise RuntimeError('hipcc failed building libdsaspp')
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB, *objs]
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib, *objs]
     subprocess.check_call(cmd)
-    return LIB
+    if out is not None:
+        for obj in objs:
+            os.remove(obj)
+    return lib
 
 
 if __name__ == '__main__':

@@ -12,6 +12,15 @@ typedef unsigned short u16;
 
 int dsaspp_set_error(const char* fmt, ...);
 
+// Per-device one-time set-up (program.hip).  HIP keeps hipFuncAttributeMaxDynamicSharedMemorySize per device function and
+// any host thread may drive any device (nn.DataParallel runs one thread per device), so neither a process-wide nor a
+// thread-local flag says whether the CURRENT device has been set up: both helpers key on hipGetDevice under a mutex.
+// Raises the dynamic-LDS limit of kernel `fn` to `bytes` on the current device, once per (function, device).
+void dsaspp_lds_limit(const void* fn, int bytes);
+// Compute units of the current device that a persistent (one block per CU) kernel may occupy: the device's CU count
+// minus what dsaspp_set_comm_cus reserved, never fewer than 8.
+int dsaspp_persistent_cus(void);
+
 // persistent grouped 1x1 data gradient (dgrad_group.hip): -1 = descriptor not of its form, 0 = launched
 int dsaspp_dgrad_group_launch(const dsaspp_conv_desc& d, hipStream_t s);
 // single-source slab data gradient with a long K on a 256 x 256 tile (dgrad_wide.hip): same return convention

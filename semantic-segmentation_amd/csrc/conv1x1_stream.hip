@@ -274,12 +274,7 @@ int launch_stream(const dsaspp_conv_desc& d, hipStream_t s) {
     const int nq = (d.cout + BQ - 1) / BQ;
     const size_t lds = (size_t)NSLOT * BQ * 128 + (size_t)(2 * d.cin + 2 * BQ) * sizeof(float);
     auto kern = conv1x1_stream_kernel<BQ>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return dsaspp_set_error("conv1x1_stream: cannot raise the LDS limit: %s", hipGetErrorString(e));
-        attr_done = true;
-    }
+    dsaspp_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(nblocks, nq), dim3(NT), lds, s, d, (int)M, nblocks);
     DS_LAUNCH_CHECK("conv1x1_stream");
     return 0;

@@ -202,11 +202,7 @@ int launch_halo(const dsaspp_conv_desc& d, hipStream_t s) {
     const size_t lds = (size_t)(TW + 2 * DIL) * (TH + 2 * DIL) * ROWB + (size_t)9 * MQ * 16 * 128;
     if (lds > 160 * 1024) return -1;                    // patch + filter slice do not fit: generic kernel
     auto kern = conv3x3_halo_kernel<MQ, DIL>;
-    static thread_local bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        done = true;
-    }
+    dsaspp_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NT), lds, s, d, tiles_x, tiles_y, nblocks);
     DS_LAUNCH_CHECK("conv_fwd(3x3 halo)");
     return 0;

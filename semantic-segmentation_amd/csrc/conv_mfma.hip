@@ -645,13 +645,7 @@ int launch_mode(const dsaspp_conv_desc& d, hipStream_t s) {
     const size_t lds = (size_t)(BP + BQ * ((WP * WQ == 8 && BP < 256 && DSASPP_DMAW != 0) ? 2 : 1)) * BK * 2 + ((PRO != 0 && d.in_scale) ? (size_t)d.cin * 8 : 0) + (EPI == 3 ? (size_t)BQ * 8 : 0);
     DS_REQUIRE(lds <= 160 * 1024, "conv_fwd: LDS request %zu too large", lds);
     auto kern = conv_kernel<BP, BQ, WP, WQ, PRO, EPI>;
-    if (lds > 64 * 1024) {
-        static thread_local bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            done = true;
-        }
-    }
+    if (lds > 64 * 1024) dsaspp_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * WP * WQ), lds, s, d, M, nQ, nblocks);
     DS_LAUNCH_CHECK("conv_fwd");
     return 0;

@@ -387,13 +387,11 @@ static int conv_wide_launch_t(const dsaspp_conv_desc& d, hipStream_t s) {
     a.nP = (a.M + BP - 1) / BP;
     a.nQ = (d.cout + BQ - 1) / BQ;
     a.relu_bits = d.in_relu ? 0u : 0x80008000u;
-    static thread_local int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    const int n_cu = dsaspp_persistent_cus();
+    {
         const void* kernels[] = {(const void*)conv_wide_kernel<BQ, true, true>, (const void*)conv_wide_kernel<BQ, true, false>,
                                  (const void*)conv_wide_kernel<BQ, false, true>, (const void*)conv_wide_kernel<BQ, false, false>};
-        for (const void* f : kernels) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (const void* f : kernels) dsaspp_lds_limit(f, 160 * 1024);
     }
     const int64_t tiles = (int64_t)a.nP * a.nQ;
     int grid = (int)((tiles + 7) / 8 * 8);

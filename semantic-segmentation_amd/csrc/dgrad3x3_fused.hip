@@ -334,12 +334,7 @@ int launch_fused(const dsaspp_conv_desc& d, hipStream_t s) {
     const int64_t nb = (int64_t)d.n_img * tiles_x * tiles_y;
     DS_REQUIRE(nb < (1ll << 31), "conv_fwd(3x3 data gradient with read-out): grid too large");
     auto kern = dgrad3x3_fused_kernel<CIN, COUT, DIL>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        DS_REQUIRE(e == hipSuccess, "conv_fwd(3x3 data gradient with read-out): cannot raise the LDS limit: %s", hipGetErrorString(e));
-        attr_done = true;
-    }
+    dsaspp_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024);
     constexpr size_t lds = Geo<CIN, COUT, DIL>::LDS;
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(NT), lds, s, d, tiles_x, tiles_y, (int)nb);
     DS_LAUNCH_CHECK("conv_fwd(3x3 data gradient with read-out)");

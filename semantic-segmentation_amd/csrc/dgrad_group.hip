@@ -672,17 +672,14 @@ int dsaspp_dgrad_group_launch(const dsaspp_conv_desc& d, hipStream_t s) {
     a.M = (int)M64;
     a.nP = (a.M + BP - 1) / BP;
     a.nQ = (d.cout + BQ - 1) / BQ;
-    static thread_local int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-            n_cu = 256;
+    const int n_cu = dsaspp_persistent_cus();
+    {
         const void* kernels[] = {
             (const void*)dgrad_group_kernel<false, false, 0>, (const void*)dgrad_group_kernel<false, true, 0>, (const void*)dgrad_group_kernel<true, false, 0>,
             (const void*)dgrad_group_kernel<true, true, 0>,   (const void*)dgrad_group_kernel<false, false, 2>, (const void*)dgrad_group_kernel<false, true, 2>,
             (const void*)dgrad_group_kernel<true, false, 2>,  (const void*)dgrad_group_kernel<true, true, 2>,   (const void*)dgrad_group_kernel<false, false, 3>,
             (const void*)dgrad_group_kernel<false, true, 3>,  (const void*)dgrad_group_kernel<true, false, 3>,  (const void*)dgrad_group_kernel<true, true, 3>};
-        for (const void* f : kernels) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        for (const void* f : kernels) dsaspp_lds_limit(f, LDS_BYTES);
     }
     int64_t tiles = (int64_t)a.nP * a.nQ;
     int grid = (int)((tiles + 7) / 8 * 8);

@@ -432,15 +432,11 @@ int dsaspp_dgrad_wide_launch(const dsaspp_conv_desc& d, hipStream_t s) {
     a.nP = (a.M + BP - 1) / BP;
     a.nQ = (d.cout + BQ - 1) / BQ;
     a.accumulate = t9 ? 0 : d.g_accumulate;
-    static thread_local int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    }
+    const int n_cu = dsaspp_persistent_cus();
+    dsaspp_lds_limit(reinterpret_cast<const void*>(dgrad_wide_kernel<true, 0>), LDS_BYTES);
+    dsaspp_lds_limit(reinterpret_cast<const void*>(dgrad_wide_kernel<false, 0>), LDS_BYTES);
+    dsaspp_lds_limit(reinterpret_cast<const void*>(dgrad_wide_kernel<false, 1>), LDS_BYTES);
+    dsaspp_lds_limit(reinterpret_cast<const void*>(dgrad_wide_kernel<false, 2>), LDS_BYTES);
     const int64_t tiles = (int64_t)a.nP * a.nQ;
     int grid = (int)((tiles + 7) / 8 * 8);
     int cap = n_cu / 8 * 8;

@@ -420,10 +420,16 @@ extern "C" int dsaspp_upsample8_ce(const dsaspp_ce_desc* d, dsaspp_stream_t stre
     const int64_t grid = blocks <= 2048 ? blocks : (blocks + UPCE_TILES_PER_BLOCK - 1) / UPCE_TILES_PER_BLOCK;
     // 16-byte loads of the corner pixels: rows of 4-float groups, the last of which may reach into the row padding
     const int vec4 = ((reinterpret_cast<uintptr_t>(d->logits) & 15) == 0 && d->ldl % 4 == 0 && d->ldl >= 20) ? 1 : 0;
-    if (d->n_class == 19)
-        hipLaunchKernelGGL((upce_kernel<19, true>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *d, tiles_x, tiles_y, (int)blocks, vec4);
-    else
-        hipLaunchKernelGGL((upce_kernel<32, false>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *d, tiles_x, tiles_y, (int)blocks, 0);
+    // Any other class count runs the instantiation for the next multiple of 8: the per-lane weight columns in LDS are
+    // 2 * NC * 256 floats (16 KiB at 8 classes, 64 KiB at 32) and the row body is NC exponentials whatever n_class is.
+#define UPCE_LAUNCH(NC, EX, V4) \
+    hipLaunchKernelGGL((upce_kernel<NC, EX>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *d, tiles_x, tiles_y, (int)blocks, V4)
+    if (d->n_class == 19) UPCE_LAUNCH(19, true, vec4);
+    else if (d->n_class <= 8) UPCE_LAUNCH(8, false, 0);
+    else if (d->n_class <= 16) UPCE_LAUNCH(16, false, 0);
+    else if (d->n_class <= 24) UPCE_LAUNCH(24, false, 0);
+    else UPCE_LAUNCH(32, false, 0);
+#undef UPCE_LAUNCH
     DS_LAUNCH_CHECK("upsample8_ce");
     return 0;
 }

@@ -277,13 +277,7 @@ int launch_dw_tile(const dsaspp_dw_desc& d, int Ho, int Wo, hipStream_t s) {
     DS_REQUIRE(gx < (1ll << 31) && d.n_img <= 65535, "dwconv3x3: grid too large");
     const size_t lds = (size_t)ITH * ITW * CCH * 16;
     auto kern = dwconv3x3_tile_kernel<CCH, TH, TW, ST>;
-    if (lds > 64 * 1024) {
-        static thread_local bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            done = true;
-        }
-    }
+    if (lds > 64 * 1024) dsaspp_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (d.C / 8) / CCH, d.n_img), dim3(32 * CCH), lds, s, d, Ho, Wo, tiles_w, tiles_h * tiles_w);
     DS_LAUNCH_CHECK("dwconv3x3(tile)");
     return 0;
@@ -364,9 +358,13 @@ extern "C" int dsaspp_dwconv3x3(const dsaspp_dw_desc* dp, dsaspp_stream_t stream
         static const int direct = [] { const char* e = getenv("DSASPP_DW_DIRECT"); return e ? atoi(e) : 0; }();
         if (!direct) {
             const int rc = launch_dw_tiled(d, Ho, Wo, (hipStream_t)stream);
-            if (rc >= 0) return rc;
+            if (rc >= 0) {
+                dsaspp_note_route("dwconv_tile");
+                return rc;
+            }
         }
     }
+    dsaspp_note_route("dwconv_direct");
     const int nb = grid_blocks(total, cg);
     hipLaunchKernelGGL(dwconv3x3_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, d, Ho, Wo, cg, (int)total);
     DS_LAUNCH_CHECK("dwconv3x3");

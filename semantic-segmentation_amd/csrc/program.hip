@@ -17,6 +17,50 @@ int dsaspp_set_error(const char* fmt, ...) {
     return 1;
 }
 
+// ---------------------------------------------------------------- per-device set-up
+#include <atomic>
+#include <mutex>
+#include <set>
+#include <utility>
+namespace {
+std::mutex g_setup_mutex;
+std::set<std::pair<const void*, int>> g_lds_done;     // (kernel, device) pairs whose LDS limit has been raised
+int g_cu_count[64];                                   // CU count per device, 0 = not looked up yet
+std::atomic<int> g_comm_cus{0};
+}  // namespace
+
+void dsaspp_lds_limit(const void* fn, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(g_setup_mutex);
+    if (g_lds_done.insert(std::make_pair(fn, dev)).second)
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+int dsaspp_persistent_cus(void) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        std::lock_guard<std::mutex> lock(g_setup_mutex);
+        if (g_cu_count[dev] == 0) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+            g_cu_count[dev] = v;
+        }
+        n = g_cu_count[dev];
+    } else {
+        n = 256;
+    }
+    n -= g_comm_cus.load(std::memory_order_relaxed);
+    return n < 8 ? 8 : n;
+}
+
+extern "C" int dsaspp_set_comm_cus(int32_t n) {
+    DS_REQUIRE(n >= 0 && n <= 128, "set_comm_cus: the number of reserved compute units must be in [0, 128] (got %d)", n);
+    g_comm_cus.store(n, std::memory_order_relaxed);
+    return 0;
+}
+extern "C" int dsaspp_get_comm_cus(void) { return g_comm_cus.load(std::memory_order_relaxed); }
+
 extern "C" int dsaspp_version(void) { return 2; }
 #ifndef DSASPP_SOURCE_HASH
 #define DSASPP_SOURCE_HASH "unknown"

@@ -252,11 +252,7 @@ int dsaspp_wgrad3x3_strip_launch(const dsaspp_wgrad_desc& d, hipStream_t s) {
     const int64_t hw = (int64_t)d.H * d.W;
     if (hw * d.ldx * 2 >= (1ll << 32) || hw * d.lddz * 2 >= (1ll << 32)) return -1;
     if ((((uintptr_t)d.x | (uintptr_t)d.dz) & 15) != 0 || (d.in_scale && ((((uintptr_t)d.in_scale | (uintptr_t)d.in_shift) & 15) != 0))) return -1;
-    static thread_local int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = dsaspp_persistent_cus();
     SArgs a;
     a.x = reinterpret_cast<const u16*>(d.x);
     a.dz = reinterpret_cast<const u16*>(d.dz);

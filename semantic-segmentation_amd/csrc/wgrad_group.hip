@@ -308,11 +308,7 @@ int launch_group(const WGArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)NZ * BKP * (BQ / 8 + 1) * 16 + 2 * (size_t)BKP * XS * 2 + (size_t)NSRC * 2 * BC * 4 + (size_t)NW * 2048;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = wgrad_group_kernel<BQ, NSRC>;
-    static thread_local bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        done = true;
-    }
+    dsaspp_lds_limit(reinterpret_cast<const void*>(kern), (int)lds);
     const int ksplit = (a.M + a.chunk - 1) / a.chunk;
     hipLaunchKernelGGL(kern, dim3(a.nC * ksplit), dim3(NT), lds, s, a);
     DS_LAUNCH_CHECK("conv_wgrad(grouped)");
@@ -364,12 +360,7 @@ int dsaspp_wgrad_group_launch(const dsaspp_wgrad_desc& d, hipStream_t s) {
     a.M = (int)M64;
     a.nC = (a.cin[0] + BC - 1) / BC;
     a.nsrc = n;
-    static thread_local int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-            n_cu = 256;
-    }
+    const int n_cu = dsaspp_persistent_cus();
     // one resident block per CU: as many pixel ranges as fit in one round, each at least 4 K-steps long
     int ksplit = d.ksplit > 0 ? d.ksplit : n_cu / a.nC;
     const int max_split = (a.M + 4 * BKP - 1) / (4 * BKP);

@@ -301,13 +301,7 @@ int launch_rt(const dsaspp_wgrad_desc& d, hipStream_t s) {
     if (red > lds) lds = red;
     DS_REQUIRE(lds <= 160 * 1024, "conv_wgrad: LDS request %zu too large", lds);
     auto kern = wgrad_kernel<BQ, BC, WQ, WC, PRO, RT, KG>;
-    if (lds > 64 * 1024) {
-        static thread_local bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            done = true;
-        }
-    }
+    if (lds > 64 * 1024) dsaspp_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(base_blocks * ksplit), dim3(64 * WQ * WC * KG), lds, s, d, M, nQ, nC, chunk);
     DS_LAUNCH_CHECK("conv_wgrad");
     return 0;

@@ -306,13 +306,9 @@ int dsaspp_wgrad_wide_launch(const dsaspp_wgrad_desc& d, hipStream_t s) {
     const int64_t M64 = (int64_t)d.n_img * d.H * d.W;
     if (M64 >= (1ll << 31)) return -1;
     if ((((uintptr_t)d.x | (uintptr_t)d.dz) & 15) != 0 || (d.in_scale && ((((uintptr_t)d.in_scale | (uintptr_t)d.in_shift) & 15) != 0))) return -1;
-    static thread_local int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-        (void)hipFuncSetAttribute((const void*)wgrad_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
+    const int n_cu = dsaspp_persistent_cus();
+    dsaspp_lds_limit((const void*)wgrad_wide_kernel<false>, 160 * 1024);
+    dsaspp_lds_limit((const void*)wgrad_wide_kernel<true>, 160 * 1024);
     // the row of zeros of the 3x3 form: one copy per GPU, its address looked up once per device and thread
     static thread_local int zero_dev = -1;
     static thread_local const unsigned char* zero_ptr = nullptr;

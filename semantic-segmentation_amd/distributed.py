@@ -13,6 +13,12 @@ import torch
 import torch.distributed as dist
 
 
+# Compute units left to the collectives while buckets are in flight (of 256 on an MI355X).  RCCL's ring / tree kernels use
+# a few dozen workgroups; 16 CUs = two per XCD cost the persistent kernels 6 % of their grid during the overlapped part of
+# the backward pass only (bench.py --force-reducer --comm-cus N measures a setting on one GPU).
+DEFAULT_COMM_CUS = 16
+
+
 def broadcast_model(model, src=0, group=None):
     """Make every rank start from rank `src`'s replica: the flat fp32 parameter arena and every buffer (BatchNorm
     running statistics and batch counters) are broadcast, as DistributedDataParallel does when it wraps a module."""
@@ -22,6 +28,9 @@ def broadcast_model(model, src=0, group=None):
     dist.broadcast(model._flat, src=src, group=group)
     for _, b in model.named_buffers():
         dist.broadcast(b, src=src, group=group)
+    # the bf16 / transposed shadow copies the kernels read were made from the old arena contents
+    if getattr(model, '_backend', None) is not None:
+        model.refresh_weights()
 
 
 def all_reduce_mean(t, group=None):
@@ -34,10 +43,14 @@ def all_reduce_mean(t, group=None):
 
 
 class GradReducer:
-    def __init__(self, model, engine, bucket_mb=25.0, group=None, always=False, broadcast=True):
+    def __init__(self, model, engine, bucket_mb=25.0, group=None, always=False, broadcast=True, comm_cus=None):
         self.model, self.engine, self.group = model, engine, group
         self.always = always             # issue the collectives even in a one-rank group (rehearsal of the N > 1 path)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # Compute units the persistent (one block per CU) kernels of the backward pass leave free while collectives are
+        # in flight, so that RCCL's reduction kernels have somewhere to run beside them (dsaspp_set_comm_cus).  Only
+        # applied when collectives are actually issued; None = DEFAULT_COMM_CUS, 0 = none.
+        self.comm_cus = DEFAULT_COMM_CUS if comm_cus is None else int(comm_cus)
         if broadcast:
             broadcast_model(model, 0, group)
         gflat = model._gflat
@@ -83,15 +96,26 @@ class GradReducer:
         gflat = self.model._gflat
         handles = []
         pos = 0
-        for lo, hi, ready in self.buckets:
-            end = ready + 1
-            if end > pos:
-                eng._bwd.run(first=pos, last=end)
-                pos = end
-            if self.world > 1 or self.always:
-                handles.append(dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        if pos < self.n_ops:
-            eng._bwd.run(first=pos, last=self.n_ops)
+        comm = self.world > 1 or self.always
+        reserve = comm and self.comm_cus > 0 and hasattr(eng.backend, 'lib')
+        if reserve:
+            from . import _lib
+            before = _lib.get_comm_cus()
+        try:
+            for lo, hi, ready in self.buckets:
+                end = ready + 1
+                if end > pos:
+                    eng._bwd.run(first=pos, last=end)
+                    pos = end
+                if comm:
+                    handles.append(dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    if reserve and len(handles) == 1:
+                        _lib.set_comm_cus(self.comm_cus)       # from the first collective on: launches read it one by one
+            if pos < self.n_ops:
+                eng._bwd.run(first=pos, last=self.n_ops)
+        finally:
+            if reserve:
+                _lib.set_comm_cus(before)
         for h in handles:
             h.wait()
         # the collectives summed: the optimizer divides (FusedAdam.step reads this when no grad_scale is passed;

@@ -62,6 +62,9 @@ class FusedAdam:
         self._moments()
         if grad_scale is None:
             grad_scale = getattr(mod, '_grad_scale', 1.0)
+        # the scale a GradReducer left belongs to the gradients of THAT backward pass: used once, then back to 1, so
+        # that a later step on locally computed gradients (train_step without a reducer, loss.backward()) is not scaled
+        mod._grad_scale = 1.0
         g0 = mod._first_param.grad
         if g0 is None or g0.data_ptr() != mod._gflat.data_ptr() + 4 * mod.arena.by_name[mod._param_names[0]].off:
             mod.sync_grads_to_arena()         # gradients came from loss.backward() through model(x), not from train_step

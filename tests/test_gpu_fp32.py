@@ -190,4 +190,7 @@ def test_bf16_default_gradients_against_the_fp32_form():
           % (rel, cos, e_cls, e_aspp, loss16, loss32))
     assert abs(loss16 - loss32) < 2e-3 * abs(loss32)
     assert e_cls < 0.06 and e_aspp < 0.12, (e_cls, e_aspp)
-    assert cos > 0.5 and rel < 1.0, (rel, cos, worst)
+    # At random initialisation only (measured 0.82 / 0.66, stable from run to run to two digits); the tolerance of the
+    # default path that one can train on is taken away from initialisation, where norm5's backward no longer cancels
+    # nearly all of its input: tests/test_gpu_trajectory.py::test_gradients_away_from_initialisation (cos > 0.99).
+    assert cos > 0.58 and rel < 0.92, (rel, cos, worst)

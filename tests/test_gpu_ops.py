@@ -612,3 +612,70 @@ def test_upsample_ce(shape):
               out=Ref(torch.randn(n * nc * 64 * h * w, generator=gen)), argmax=None)
     out = run_both('up_bwd', fb)
     close(out['logits'][0], out['logits'][1], 1e-4, 'up_bwd.dlogits')
+
+
+@pytest.mark.parametrize('nc,ldl,shape', [(7, 8, (2, 4, 6)), (7, 32, (1, 6, 10, 'peaks')), (16, 16, (1, 5, 3)), (21, 24, (2, 3, 9)),
+                                          (21, 32, (1, 6, 10, 'peaks')), (24, 32, (1, 8, 16)), (32, 32, (1, 37, 21)),
+                                          (32, 32, (1, 6, 10, 'peaks')), (1, 4, (1, 2, 3))])
+def test_upsample_ce_other_class_counts(nc, ldl, shape):
+    """Class counts other than 19 run the range-checked instantiations (padding classes at -1e30, one per multiple of
+    8 classes): loss, count, gradient, bf16 copy and bias gradient against the kernel model."""
+    n, h, w = shape[:3]
+    gen = torch.Generator().manual_seed(1000 * nc + h * w)
+    M = n * h * w
+    logits = torch.randn(M * ldl, generator=gen) * 2
+    if len(shape) > 3:
+        lv = logits.view(M, ldl)
+        lv[torch.arange(M), torch.arange(M) % nc] += 400.0
+    labels = torch.randint(0, nc, (n * 64 * h * w,), generator=gen)
+    labels[torch.rand(labels.shape, generator=gen) < 0.1] = 255
+    f = dict(n_img=n, h=h, w=w, n_class=nc, ldl=ldl, logits=Ref(logits), labels=Ref(labels), ignore_index=255,
+             dlogits=Ref(torch.zeros(M * ldl)), accum=Ref(torch.zeros(1024)), grad_scale=1.0, loss=Ref(torch.zeros(1)),
+             dlogits_bf16=Ref(torch.zeros(M * 32, dtype=torch.bfloat16)), lddb=32, dbias=Ref(torch.zeros(32)))
+    out = run_both('upce', f)
+    close(out['accum'][0].view(32, 32).sum(0)[:2], out['accum'][1].view(32, 32).sum(0)[:2], 1e-4, 'upce.accum')
+    close(out['dlogits'][0], out['dlogits'][1], 1e-4, 'upce.dlogits')
+    # nothing is written into the row padding past n_class
+    assert bool((out['dlogits'][1].view(M, ldl)[:, nc:] == 0).all())
+    out = run_both('ce_finalize', f)
+    close(out['loss'][0], out['loss'][1], 1e-4, 'ce_finalize.loss')
+    close(out['dlogits'][0], out['dlogits'][1], 1e-4, 'ce_finalize.dlogits')
+    close(out['dlogits_bf16'][0], out['dlogits_bf16'][1], 1e-2, 'ce_finalize.dlogits16')
+    close(out['dbias'][0], out['dbias'][1], 1e-3, 'ce_finalize.dbias')
+
+
+@pytest.mark.parametrize('nc', [7, 19, 21])
+def test_upsample_ce_live_label_outside_the_classes(nc):
+    """A label that is neither ignore_index nor a class (the reference's CrossEntropyLoss raises on it): the pixel counts,
+    contributes its log-sum-exp to the loss and the plain softmax to the gradient -- there is no class to subtract."""
+    import torch.nn.functional as F
+    from semantic_segmentation_amd.backend import HipBackend
+    n, h, w, ldl = 1, 5, 7, 32
+    gen = torch.Generator().manual_seed(nc)
+    M = n * h * w
+    logits = torch.randn(M * ldl, generator=gen) * 2
+    labels = torch.randint(0, nc, (n * 64 * h * w,), generator=gen)
+    r = torch.rand(labels.shape, generator=gen)
+    labels[r < 0.1] = 255
+    labels[(r >= 0.1) & (r < 0.2)] = nc + 3            # live, outside [0, nc)
+    lg = logits.view(M, ldl)[:, :nc].view(n, h, w, nc).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    full = F.interpolate(lg, scale_factor=8, mode='bilinear', align_corners=False)
+    lab = labels.view(n, 8 * h, 8 * w)
+    lse = torch.logsumexp(full, 1)
+    valid = lab < nc
+    live = lab != 255
+    tgt = full.gather(1, lab.clamp(max=nc - 1)[:, None])[:, 0]
+    loss_sum = (lse * live).sum() - (tgt * valid).sum()
+    loss_sum.backward()
+    want_g = lg.grad.permute(0, 2, 3, 1).reshape(M, nc)
+    be = HipBackend()
+    dev = {k: v.cuda() for k, v in dict(logits=logits, labels=labels, dlogits=torch.zeros(M * ldl), accum=torch.zeros(1024)).items()}
+    be.call('upce', n_img=n, h=h, w=w, n_class=nc, ldl=ldl, logits=Ref(dev['logits']), labels=Ref(dev['labels']), ignore_index=255,
+            dlogits=Ref(dev['dlogits']), accum=Ref(dev['accum']), grad_scale=1.0, loss=None, dlogits_bf16=None, lddb=0, dbias=None)
+    torch.cuda.synchronize()
+    acc = dev['accum'].cpu().view(32, 32).sum(0)
+    assert abs(float(acc[1]) - float(live.sum())) < 0.5
+    assert abs(float(acc[0]) - float(loss_sum)) < 1e-4 * abs(float(loss_sum))
+    got = dev['dlogits'].cpu().view(M, ldl)
+    assert float((got[:, :nc] - want_g).abs().max()) < 1e-4 * float(want_g.abs().max())
+    assert bool((got[:, nc:] == 0).all())
