@@ -7,12 +7,13 @@ the depthwise kernel on the full 128 x 256 map of the dilated blocks against the
   * eval logits are bit-identical for the last image alone and inside the batch of 16, and across repeated runs;
   * the three output forms (full-resolution logits, fused arg-max, confusion-matrix arg-max) agree, confusion counts are
     conserved;
-  * bf16 form against the fp32 form of the same network (which reproduces the oracle to 1e-5 at small sizes).
+  * fp32 form and bf16 form against the oracle at 1 x 1024 x 2048.
 
-bf16 tolerance of this variant, as a number: root-mean-square logit error <= 0.2 of the root-mean-square logit
-(measured 0.09-0.11 at random initialisation).  Why not the DenseNet variants' 2e-2: rounding ONLY the oracle's own conv
-weights and its input to bf16 already moves its logits by 9 % -- a randomly initialised 52-convolution MobileNetV2
-trunk amplifies a perturbation 1.2-1.5x per block, there is no dense connectivity to carry early features forward.
+bf16 tolerance of this variant, as numbers: root-mean-square logit error <= 0.25 of the root-mean-square logit at
+1024 x 2048 (measured 0.16), <= 0.2 at 64 x 128 (measured 0.12, tests/test_gpu_mobilenet.py).  Why not the DenseNet
+variants' 2e-2: rounding ONLY the oracle's own conv weights and its input to bf16 already moves its logits by 12 % at
+this size -- a randomly initialised 52-convolution MobileNetV2 trunk amplifies a perturbation 1.2-1.5x per block, there
+is no dense connectivity to carry early features forward.  The fp32 form of the same kernels is within 1e-4 at this size.
 """
 import pytest
 import torch
@@ -23,7 +24,7 @@ import kernel_model  # noqa: E402,F401
 from optools import Ref, bf, close, run_both  # noqa: E402
 
 H, W = 1024, 2048
-MOBILENET_BF16_RMS_TOL = 0.2
+MOBILENET_BF16_FULLSIZE_TOL = 0.25
 
 
 def _lib():
@@ -129,32 +130,53 @@ def test_output_forms_agree_and_counts_are_conserved(mobilenet):
     assert torch.equal(conf.sum(0), torch.bincount(am.flatten(), minlength=19))
 
 
-def test_bf16_against_the_fp32_form_at_full_size(mobilenet):
-    m = mobilenet
-    x, _ = _batch(1, 43)
+def test_full_size_against_the_oracle():
+    """1 x 1024 x 2048 against the fp32 oracle (about a second on the host cores for this small network).
+
+    fp32 form of the kernels, randomised BatchNorm tables: within 1e-4 -- planner and kernels are right at this size.
+    bf16 default, BatchNorm tables as constructed: root-mean-square error within MOBILENET_BF16_FULLSIZE_TOL of the
+    root-mean-square logit (measured 0.16), and within 1.6x of what the ORACLE ITSELF moves when only its conv weights and
+    input are rounded to bf16 (measured 0.12 at this size; the ratio is 1.25-1.4 at every size tried).  The error of
+    this variant grows with the image: at 64 x 128 most taps of the dilated depthwise layers read padding."""
+    from e2e_common import make_batch
+    from test_mobilenet_cpu import bf16_yardstick, make_mobilenet_pair, rms_rel
+    torch.set_num_threads(16)
+    x, _ = make_batch(1, H, W)
+    # ---- fp32 form
+    ref, mod = make_mobilenet_pair()
+    ref.eval()
     with torch.no_grad():
-        y16 = m.forward_lowres(x).float()
-    m._engines.clear()
+        yr = ref.forward_lowres(x)
+    mod = mod.cuda().eval().set_compute_dtype(torch.float32)
+    with torch.no_grad():
+        y32 = mod.forward_lowres(x.cuda()).cpu()
+    e32 = rms_rel(yr, y32)
+    print('MobileNetDenseASPP 1x1024x2048 fp32 form vs oracle: rms %.3e, max|d|/max|ref| %.3e'
+          % (e32, float((yr - y32).abs().max() / yr.abs().max())))
+    assert e32 < 1e-4                                    # measured 3.6e-5
+    assert float((yr - y32).abs().max() / yr.abs().max()) < 1e-3
+    mod._engines.clear()
+    del mod
     torch.cuda.empty_cache()
-    m.set_compute_dtype(torch.float32)
-    try:
-        with torch.no_grad():
-            y32 = m.forward_lowres(x).float()
-    finally:
-        m.set_compute_dtype(torch.bfloat16)
-        m._engines.clear()
-        torch.cuda.empty_cache()
-    rms = float((y16 - y32).pow(2).mean().sqrt() / y32.pow(2).mean().sqrt())
-    mx = float((y16 - y32).abs().max() / y32.abs().max())
-    scale = float(y32.abs().max())
-    top2 = y32.topk(2, dim=1).values
-    clear = (top2[:, 0] - top2[:, 1]) > 2 * mx * scale
-    same = y16.argmax(1) == y32.argmax(1)
-    print('MobileNetDenseASPP 1x1024x2048 bf16 vs fp32 form: rms %.3e, max|d|/max|ref| %.3e, arg-max agreement %.4f overall'
-          % (rms, mx, float(same.float().mean())))
-    assert rms < MOBILENET_BF16_RMS_TOL
+    # ---- bf16 default
+    ref, mod = make_mobilenet_pair()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.reset_parameters()
+    mod.load_state_dict(ref.state_dict())
+    ref.eval()
+    with torch.no_grad():
+        yr = ref.forward_lowres(x)
+    yard = bf16_yardstick(ref, x)
+    mod = mod.cuda().eval()
+    with torch.no_grad():
+        y16 = mod.forward_lowres(x.cuda()).cpu()
+    e16 = rms_rel(yr, y16)
+    print('MobileNetDenseASPP 1x1024x2048 bf16 vs oracle: rms %.3e (oracle with bf16 weights and input: %.3e)' % (e16, yard))
+    assert e16 < MOBILENET_BF16_FULLSIZE_TOL
+    assert e16 < 1.6 * yard
     # the bottom-right corner of the map lies at the far end of every buffer
-    corner = float((y16[..., -8:, -8:] - y32[..., -8:, -8:]).pow(2).mean().sqrt() / y32.pow(2).mean().sqrt())
-    assert corner < 2 * MOBILENET_BF16_RMS_TOL
-    if bool(clear.any()):
-        assert bool(same[clear].all())
+    corner = float((yr[..., -8:, -8:] - y16[..., -8:, -8:]).pow(2).mean().sqrt() / yr.pow(2).mean().sqrt())
+    assert corner < 2 * MOBILENET_BF16_FULLSIZE_TOL
+    mod._engines.clear()
+    torch.cuda.empty_cache()
