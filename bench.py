@@ -67,6 +67,84 @@ def cpu_baseline(cfg, budget_s=40.0):
                        % (H, W, t, times[0], times[-1]))
 
 
+def reference_loop_rate(model, x, labels, steps=3, warmup=1):
+    """The reference's own training loop (graph_seg_main.py:231-245) on the same model and batch:
+    optimizer.zero_grad(); output = model(x); loss = CrossEntropyLoss(ignore_index=255)(output, gt); loss.backward();
+    torch.optim.Adam.step() -- full-resolution fp32 logits are materialised and torch computes the loss on them."""
+    crit = torch.nn.CrossEntropyLoss(ignore_index=255).to(x.device)
+    opt = torch.optim.Adam(model.parameters(), weight_decay=1e-4, lr=1e-4)
+    model.train()
+
+    def one():
+        opt.zero_grad()
+        loss = crit(model(x), labels)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / steps
+    return dict(value=round(x.shape[0] / dt, 3), unit='img/s', ms_per_step=round(1e3 * dt, 2), batch=x.shape[0], steps=steps,
+                loss=round(float(loss), 5),
+                loop='zero_grad; model(x) -> fp32 NCHW logits; CrossEntropyLoss(ignore_index=255); backward(); torch.optim.Adam.step()')
+
+
+def config4_rate(device, H, W, steps=3, warmup=1, reserve=0.12):
+    """BASELINE config 4: DenseASPP201 training at 1024x2048 with the largest per-GPU batch that fits the HBM.  The
+    batch is found from the memory one engine of 4 images takes: whole multiples of 8 images that leave `reserve` of the
+    device memory free."""
+    import importlib
+    import denseASPP
+    from semantic_segmentation_amd.optim import FusedAdam
+    cfg = importlib.import_module('cfgs.DenseASPP201').Model_CFG
+    torch.manual_seed(0)
+    model = denseASPP.DenseASPP(cfg, n_class=19, output_stride=8).to(device).train()
+    opt = FusedAdam(model, lr=1e-4, weight_decay=1e-4)
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    model.engine(4, H, W, True)
+    per_img = (torch.cuda.memory_allocated() - base) / 4.0
+    model._engines.clear()
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    fixed = 8 * 4 * sum(p.numel() for p in model.parameters())       # Adam moments + staging that appear with the first step
+    B = int((free - reserve * total - fixed) / (per_img + 3 * 4 * H * W + 8 * H * W))
+    B = max(8, min(B // 8 * 8, 96))
+    x, labels = synth_batch(B, H, W, 0, device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(7)
+    model.engine(B, H, W, True)
+    model.refresh_weights()
+
+    def one():
+        loss = model.train_step(x, labels, generator=gen, refresh=False)
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / steps
+    out = dict(model='DenseASPP201', batch=B, value=round(B / dt, 3), unit='img/s', ms_per_step=round(1e3 * dt, 2), steps=steps,
+               loss=round(float(loss), 5), gb_per_image=round(per_img / 1e9, 3),
+               gb_allocated=round(torch.cuda.max_memory_allocated() / 1e9, 1),
+               mfma_peak_frac_whole_step=round(6.0 * model.conv_macs(H, W) * B / dt / 1e12 / PEAK_BF16_TFLOPS, 4))
+    model._engines.clear()
+    del model, opt, x, labels
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -86,6 +164,8 @@ def main():
     ap.add_argument('--side-wgrad3', action='store_true', help='dense-layer 3x3 weight gradients on a second stream')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the two extra measurements of a one-GPU run: the reference-shaped loop and BASELINE config 4')
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line: libraries that print to fd 1 (RCCL writes a version banner there when a
@@ -204,31 +284,38 @@ def main():
         t = dom_tag
         d = dict(launches_per_step=n, avg_us=1e3 * ms[t] / cnt[t], ms_per_step=ms[t] / args.steps,
                  tflops=fl * args.steps / (ms[t] * 1e-3) / 1e12, gbs=(by * args.steps / (ms[t] * 1e-3) / 1e9) if by else None)
-        kernels[dom] = d
-        traffic = None                      # HBM bytes per launch from the committed PMC passes of this same build
+        kernels[dom].update(d)
+        # HBM bytes per launch from the committed PMC passes of this same build, per kernel class (bytes per launch scale
+        # with the batch and change with the kernels: a record of another build or batch is not reported)
+        traffic_tab = {}
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
         if os.path.exists(tpath):
             from semantic_segmentation_amd import _lib
             tj = json.load(open(tpath))
             meta = tj.get('_meta') or {}
-            # bytes per launch scale with the batch and change with the kernels: a record of another build is not reported
             if meta.get('batch') == args.batch and meta.get('source_hash') == _lib.source_hash():
-                traffic = (tj.get(dom) or {}).get('hbm_bytes_per_launch')
-        # Which roof bounds the dominant kernel class: its algorithmic intensity (flops per algorithmic byte, every
-        # operand moved once) against the ridge of the machine
+                traffic_tab = {k: v.get('hbm_bytes_per_launch') for k, v in tj.items() if isinstance(v, dict) and k != '_meta'}
+        for kname, kv in kernels.items():
+            fl_k, by_k, n_k = per_run[profiling.CLASSES.index(kname)]
+            kv['alg_bytes_per_launch'] = round(by_k / n_k) if n_k else None
+            kv['traffic'] = traffic_tab.get(kname)
+            kv['traffic_over_alg'] = round(kv['traffic'] / kv['alg_bytes_per_launch'], 3) if kv['traffic'] and kv['alg_bytes_per_launch'] else None
+        traffic = traffic_tab.get(dom)
+        # Every convolution is priced against the MFMA roof (dense contraction), whatever its algorithmic intensity says:
+        # the basis on which the fractions of successive builds are comparable.  The HBM side of the same launches is
+        # carried beside it (hbm_gbs / hbm_frac of the algorithmic bytes, flop_per_byte against the ridge of the machine,
+        # and `binding`: which of the two roofs the algorithmic intensity puts the class under).
         intensity = d['tflops'] * 1e12 / (d['gbs'] * 1e9) if d.get('gbs') else float('inf')
         ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
-        common = dict(kernel=dom, traffic=traffic, avg_launch_us=round(d['avg_us'], 2), launches_per_step=d['launches_per_step'],
-                      flop_per_byte=round(intensity, 1), ridge_flop_per_byte=round(ridge, 1),
-                      mfma_tflops=round(d['tflops'], 2), mfma_frac=round(d['tflops'] / PEAK_BF16_TFLOPS, 4),
-                      hbm_gbs=round(d['gbs'], 1) if d.get('gbs') else None,
-                      hbm_frac=round(d['gbs'] / PEAK_HBM_GBS, 4) if d.get('gbs') else None)
-        if intensity < ridge:
-            roofline = dict(bound='hbm', achieved=round(d['gbs'], 1), peak=PEAK_HBM_GBS, unit='GB/s',
-                            frac=round(d['gbs'] / PEAK_HBM_GBS, 4), **common)
-        else:
-            roofline = dict(bound='mfma', achieved=round(d['tflops'], 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
-                            frac=round(d['tflops'] / PEAK_BF16_TFLOPS, 4), **common)
+        roofline = dict(bound='mfma', achieved=round(d['tflops'], 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
+                        frac=round(d['tflops'] / PEAK_BF16_TFLOPS, 4), kernel=dom, traffic=traffic,
+                        alg_bytes_per_launch=kernels[dom].get('alg_bytes_per_launch'),
+                        avg_launch_us=round(d['avg_us'], 2), launches_per_step=d['launches_per_step'],
+                        flop_per_byte=round(intensity, 1), ridge_flop_per_byte=round(ridge, 1),
+                        binding='hbm' if intensity < ridge else 'mfma',
+                        mfma_tflops=round(d['tflops'], 2), mfma_frac=round(d['tflops'] / PEAK_BF16_TFLOPS, 4),
+                        hbm_gbs=round(d['gbs'], 1) if d.get('gbs') else None,
+                        hbm_frac=round(d['gbs'] / PEAK_HBM_GBS, 4) if d.get('gbs') else None)
 
     if rank == 0:
         imgs = world * B * args.steps
@@ -250,6 +337,23 @@ def main():
             'kernels': {k: {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items()} for k, v in kernels.items()},
             'kernels_note': 'one untimed step with every MFMA launch between HIP events; the entry of roofline.kernel is from the timed steps',
         }
+        out['mfma_time_share'] = round(sum(v['ms_per_step'] for k, v in kernels.items() if v.get('tflops')) / (1e3 * dt / args.steps), 4) \
+            if kernels else None
+        # Two more numbers of a one-GPU run, outside the timed region above: what a user of the reference's unchanged
+        # loop gets, and BASELINE config 4.  A failure here is reported in place and leaves the headline line intact.
+        if world == 1 and not args.no_extras and not args.force_reducer:
+            try:
+                out['reference_loop'] = reference_loop_rate(model, x, labels)
+            except Exception as e:          # noqa: BLE001
+                out['reference_loop'] = {'error': '%s: %s' % (type(e).__name__, e)}
+            model._engines.clear()
+            eng = reducer = None
+            progs = []
+            torch.cuda.empty_cache()
+            try:
+                out['config4_densenet201_max_batch'] = config4_rate(device, H, W)
+            except Exception as e:          # noqa: BLE001
+                out['config4_densenet201_max_batch'] = {'error': '%s: %s' % (type(e).__name__, e)}
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(cfg)
         else:

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
     //      rows: thread t owns chunk position t & 3 of rows t >> 2 and (t >> 2) + 128 (both rows have the same swizzle).
     const uint32_t ring_l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)ring);
     int c_k = 0, c_kk = 0, c_slot = 0;
-    uint32_t w_off[2], x_off[2];                      // byte offsets of this lane's rows in w and x
+    uint32_t w_off[2], x_off[2];                      // byte offsets of this lane's rows in w and, from the tile's first row, in x
+    const u16* x_tile = a.x;                          // first pixel row of the cursor's tile (uniform; x may be larger than 4 GiB)
     // (lane- and thread-derived coordinates are formed where they are used, from an opaque copy of the thread id: kept as
     // values that live through the whole kernel they are spilled in favour of the epilogue, and a scratch reload inside
     // the K-loop is waited for with vmcnt(0), which drains the DMA queue)
@@ -132,10 +133,18 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
 #if CW_ABL_X
             p &= 1023;                                 // diagnostic build: every block reads the same cache-resident rows
 #endif
+#if CW_ABL_X
             x_off[i] = (uint32_t)p * (uint32_t)a.ldx * 2u;
+#else
+            x_off[i] = (uint32_t)(p - pb) * (uint32_t)a.ldx * 2u;
+#endif
         }
+#if !CW_ABL_X
+        x_tile = a.x + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(pb) * a.ldx;
+#endif
     };
     uint32_t xo_n[2];                                 // pixel-chunk offsets of the stage whose filter rows were requested last
+    const u16* xb_n = a.x;                            // ... and the tile base they are relative to
     int kk_n = 0;                                     // ... and its K-step
     auto issue_w = [&]() {
         const uint32_t slot_l = ring_l + c_slot * STAGE + BP * 64;
@@ -154,6 +163,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
         const uint32_t kbx = (c_kk * BK + xkc * 8 < cin) ? (uint32_t)(c_kk * BK + xkc * 8) * 2u : 0u;
         xo_n[0] = x_off[0] + kbx;
         xo_n[1] = x_off[1] + kbx;
+        xb_n = x_tile;
         kk_n = c_kk;
         c_slot = c_slot + 1 < NS ? c_slot + 1 : 0;
         if (c_k < ntile) {
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
     };
     auto issue_x = [&](u32x4 (&buf)[2], int& kk_buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(buf[i]) : "v"(xo_n[i]), "s"(a.x) : "memory");
+        for (int i = 0; i < 2; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(buf[i]) : "v"(xo_n[i]), "s"(xb_n) : "memory");
         kk_buf = kk_n;
     };
     // prologue of a landed buffer into the slot of its stage (the ring slot after the one being read)
@@ -296,9 +306,10 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
         const int qw = q_base + wq * TQ + ecc * 4;          // this lane's channel quad (cout is a multiple of 4)
         const bool qok = qin && qw < cout;
         const int cl = wq * TQ + ecc * 4;
-        const int p_w = p_base + wp * TP + er;
+        const int p_w = wp * TP + er;                       // counted from the tile's first row
+        const int m_rel = M - p_base;
         const uint32_t qoff = (uint32_t)(qok ? qw : 0) * 2u, ldy2 = (uint32_t)a.ldy * 2u;
-        unsigned char* yb = reinterpret_cast<unsigned char*>(a.y);
+        unsigned char* yb = reinterpret_cast<unsigned char*>(a.y) + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(p_base) * ldy2;      // the tile's first row: uniform 64-bit base, 32-bit offsets inside the tile
         f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.bias && qok) b4 = *reinterpret_cast<const f32x4*>(a.bias + qw);
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wide_kernel(const CWArgs a) {
                 const f32x4 a4 = *reinterpret_cast<const f32x4*>(stage + (rp * 4 + er) * ROWF + ecc * 4);
                 int p = p_w + j * 16 + rp * 4;
                 asm volatile("" : "+v"(p));
-                const bool ok = qok && p < M;
+                const bool ok = qok && p < m_rel;
                 const u32x2 o = u32x2{pack_bf2(a4[0] + b4[0], a4[1] + b4[1]), pack_bf2(a4[2] + b4[2], a4[3] + b4[3])};
                 if (STATS) {
                     const float r[4] = {bf_lo(o.x), bf_hi(o.x), bf_lo(o.y), bf_hi(o.y)};
@@ -368,7 +379,9 @@ static int conv_wide_launch_t(const dsaspp_conv_desc& d, hipStream_t s) {
     if (lds > 160 * 1024) return -1;
     const int64_t M64 = (int64_t)d.n_img * d.H * d.W;
     // operand and output offsets are 32-bit byte offsets from the tensor base
-    if (M64 * d.ldx * 2 >= (1ll << 32) || (int64_t)d.cout * d.cin * 2 >= (1ll << 32) || M64 >= (1ll << 31) || M64 * d.ldy * 2 >= (1ll << 32)) return -1;
+    // pixel rows are addressed from a uniform 64-bit tile base (tensors may exceed 4 GiB); inside a tile and in the filter,
+    // offsets are 32-bit
+    if ((int64_t)d.cout * d.cin * 2 >= (1ll << 32) || M64 >= (1ll << 31) - BP || (int64_t)BP * d.ldx * 2 >= (1ll << 31) || (int64_t)BP * d.ldy * 2 >= (1ll << 31)) return -1;
     if ((((uintptr_t)d.x | (uintptr_t)d.w) & 15) != 0 || ((uintptr_t)d.y & 7) != 0 || (d.bias && ((uintptr_t)d.bias & 15) != 0)) return -1;
     CWArgs a;
     a.x = reinterpret_cast<const u16*>(d.x);

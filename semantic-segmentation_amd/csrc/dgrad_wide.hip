@@ -108,7 +108,8 @@ __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
     //      its lane-linear LDS position
     const uint32_t ring_l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)ring);
     int c_k = 0, c_kk = 0, c_slot = 0;
-    uint32_t r_off[4];                                // byte offset of this lane's row in its tensor
+    uint32_t r_off[4];                                // byte offset of this lane's row: pixel rows from the tile's first row, filter rows in w
+    const u16* x_tile = a.x;                          // first pixel row of the cursor's tile (uniform; the operand may be larger than 4 GiB)
     int phw[2];                                       // 3x3 form: image coordinates (h << 16 | w) of this lane's two pixel rows; rows past the end: far outside
     const int lrow = lane >> 2;
     auto cursor_tile = [&]() {
@@ -125,13 +126,14 @@ __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
                     phw[i] = p < M ? (h << 16) | (rem - h * a.W) : 0x7fff7fff;
                 }
                 p = p < M ? p : M - 1;
-                r_off[i] = (uint32_t)p * (uint32_t)a.ldx * 2u;
+                r_off[i] = (uint32_t)(p - pb) * (uint32_t)a.ldx * 2u;
             } else {
                 int q = qb + row;
                 q = q < cout ? q : cout - 1;
                 r_off[i] = (uint32_t)q * (uint32_t)cin * 2u;
             }
         }
+        x_tile = a.x + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(pb) * a.ldx;
     };
     const int lchunk = (lane & 3) ^ swz(lrow);        // the K chunk this lane fetches ((i*8 + wave)*16 is a multiple of 16: swz depends on lrow only)
     auto issue = [&]() {
@@ -164,13 +166,13 @@ __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
             if (T9 && i < 2) {
                 const bool ok = tap_ok && (unsigned)((phw[i] >> 16) + dy) < (unsigned)a.H && (unsigned)((phw[i] & 0xffff) + dx) < (unsigned)a.W;
                 // (the row's own byte offset is the one of the 1x1 form; the tap's shift in bytes fits 32 bits: launcher)
-                const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(a.x) + r_off[i] + (int64_t)((dy * a.W + dx) * (a.ldx * 2)) + kx_b : a.zero;
+                const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(x_tile) + r_off[i] + (int64_t)((dy * a.W + dx) * (a.ldx * 2)) + kx_b : a.zero;
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                              : : "s"(slot_l + (i * 8 + wave) * 1024), "v"(src) : "memory");
                 continue;
             }
             const uint32_t off = r_off[i] + kb;
-            const u16* base = i < 2 ? a.x : a.w;
+            const u16* base = i < 2 ? x_tile : a.w;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                          : : "s"(slot_l + (i * 8 + wave) * 1024), "v"(off), "s"(base) : "memory");
         }
@@ -266,11 +268,14 @@ __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
         const int qw = q_base + wq * TQ + ec * 4;           // this lane's channel quad (cout is a multiple of 4)
         const bool qok = qw < cout;
         const int cl = wq * TQ + ec * 4;                     // ... inside the channel tile
-        const int p_w = p_base + wp * TP + er;               // this lane's pixel of group 0, pass 0
+        const int p_w = wp * TP + er;                        // this lane's pixel of group 0, pass 0, counted from the tile's first row
+        const int m_rel = M - p_base;                        // rows of the tensor from the tile's first row on (> 0)
         // slab addresses are a uniform base plus a 32-bit byte offset (the launcher checks that they fit)
         const uint32_t qoff = (uint32_t)(qok ? qw : 0) * 2u, ldref2 = (uint32_t)a.ldref * 2u, ldg2 = (uint32_t)a.ldg * 2u;
-        const unsigned char* refb = reinterpret_cast<const unsigned char*>(a.ref);
-        unsigned char* gb = reinterpret_cast<unsigned char*>(a.g);
+        // (the tile's first row: slabs may be larger than 4 GiB)
+        const uint32_t pb_s = __builtin_amdgcn_readfirstlane(p_base);        // (scalar arithmetic for the two bases)
+        const unsigned char* refb = reinterpret_cast<const unsigned char*>(a.ref) + (size_t)pb_s * ldref2;
+        unsigned char* gb = reinterpret_cast<unsigned char*>(a.g) + (size_t)pb_s * ldg2;
         // groups requested before the last K-step / in flight at most.  Accumulating (two loads per pass), three groups are
         // what fits beside the accumulators without a spill; with five, 17 registers went to scratch, every reload was
         // waited for with vmcnt(0) -- which also waits for the whole prefetch -- and the launches took 6-8 % longer
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
 #pragma unroll
             for (int rp = 0; rp < NRP; ++rp) {
                 int p = pj + rp * 4;
-                p = p < M ? p : M - 1;
+                p = p < m_rel ? p : m_rel - 1;
                 rfv[j][rp] = *reinterpret_cast<const u32x2*>(refb + (size_t)((uint32_t)p * ldref2 + qoff));
                 if constexpr (ACCG) gov[j][rp] = *reinterpret_cast<const u32x2*>(gb + (size_t)((uint32_t)p * ldg2 + qoff));
             }
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad_wide_kernel(const WArgs a) {
                 const f32x4 a4 = *reinterpret_cast<const f32x4*>(stage + (rp * 4 + er) * ROWF + ec * 4);
                 int p = p_w + j * 16 + rp * 4;
                 asm volatile("" : "+v"(p));
-                const bool ok = qok && p < M;
+                const bool ok = qok && p < m_rel;
                 const u32x2 rr = rfv[j][rp];
                 const float rf[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
                 float t[4];
@@ -388,9 +393,10 @@ int dsaspp_dgrad_wide_launch(const dsaspp_conv_desc& d, hipStream_t s) {
     const int64_t M64 = (int64_t)d.n_img * d.H * d.W;
     void* outp = t9 ? d.y : d.g;
     const int ldo = t9 ? d.ldy : d.ldg;
-    // operand offsets are 32-bit byte offsets from the tensor base
-    if (M64 * d.ldx * 2 >= (1ll << 32) || (int64_t)d.cout * kdim * 2 >= (1ll << 32) || M64 >= (1ll << 31) || M64 * d.ldref * 2 >= (1ll << 32) ||
-        M64 * ldo * 2 >= (1ll << 32))
+    // pixel rows of every tensor are addressed from a uniform 64-bit tile base (slabs may exceed 4 GiB); inside a tile and
+    // in the filter, offsets are 32-bit
+    if ((int64_t)d.cout * kdim * 2 >= (1ll << 32) || M64 >= (1ll << 31) - BP || (int64_t)BP * d.ldx * 2 >= (1ll << 31) ||
+        (int64_t)BP * d.ldref * 2 >= (1ll << 31) || (int64_t)BP * ldo * 2 >= (1ll << 31))
         return -1;
     if ((((uintptr_t)d.ref | (uintptr_t)outp) & 7) != 0) return -1;
     if (t9 && ((int64_t)d.dil * (d.W + 1) * d.ldx * 2 >= (1ll << 31) || d.H + d.dil >= 32000 || d.W + d.dil >= 32000)) return -1;

@@ -130,8 +130,10 @@ __global__ __launch_bounds__(NT, 2) void wgrad_group_kernel(const WGArgs a) {
     constexpr int ZMIN = Z_INSTR / NW;                   // DMA instructions every wave issues per tile (some issue one more)
     int d_stage = 0, d_k = 0, d_s = 0;                   // DMA cursor; frozen on the last tile once it is reached
     auto issue_z = [&]() {
-        const u16* base = a.dz[d_s];
-        const int m0 = m_begin + d_k * BKP;
+        // (rows are counted from the block's first row, whose address is a 64-bit scalar: the dz tensors may exceed 4 GiB)
+        const u16* base = a.dz[d_s] + (size_t)(uint32_t)m_begin * a.lddz;
+        const int m0 = d_k * BKP;
+        const int m_lim = M - 1 - m_begin;
         const uint32_t slot_l = zring_l + (uint32_t)(d_stage % NZ) * Z_BYTES;
         int lane_z = lane;                            // opaque copy: otherwise the rows and chunks below are hoisted out of the
         asm volatile("" : "+v"(lane_z));              // K-loop as eight loop-invariant registers
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_group_kernel(const WGArgs a) {
                 cc = cc < zch_ok ? cc : zch_ok - 1;
                 row = row < BKP ? row : BKP - 1;
                 int m = m0 + row;
-                m = m < M ? m : M - 1;
+                m = m < m_lim ? m : m_lim;
                 const uint32_t off = (uint32_t)m * (uint32_t)a.lddz * 2u + (uint32_t)cc * 16u;
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                              : : "s"(slot_l + (uint32_t)(t * NW + wave) * 1024u), "v"(off), "s"(base) : "memory");
@@ -356,7 +358,7 @@ int dsaspp_wgrad_group_launch(const dsaspp_wgrad_desc& d, hipStream_t s) {
     a.cout = d.cout;
     a.relu = d.in_relu;
     const int64_t M64 = (int64_t)d.n_img * d.H * d.W;
-    DS_REQUIRE(M64 * d.lddz * 2 < (1ll << 32), "conv_wgrad(grouped): dz tensors must be smaller than 4 GiB");
+    DS_REQUIRE(M64 < (1ll << 31) - 4096, "conv_wgrad(grouped): too many pixels");
     a.M = (int)M64;
     a.nC = (a.cin[0] + BC - 1) / BC;
     a.nsrc = n;
@@ -368,6 +370,8 @@ int dsaspp_wgrad_group_launch(const dsaspp_wgrad_desc& d, hipStream_t s) {
     if (ksplit < 1) ksplit = 1;
     int chunk = (a.M + ksplit - 1) / ksplit;
     a.chunk = (chunk + BKP - 1) / BKP * BKP;
+    // dz rows are addressed by 32-bit byte offsets from the block's first row
+    DS_REQUIRE(((int64_t)a.chunk + BKP) * d.lddz * 2 < (1ll << 32), "conv_wgrad(grouped): pixel range of a block too long (%d rows)", a.chunk);
     const bool wide = d.cout > 128;
 #define WGG_PICK(N_)                                                 \
     return wide ? launch_group<192, N_>(a, s) : launch_group<128, N_>(a, s)

@@ -330,12 +330,18 @@ int dsaspp_wgrad_wide_launch(const dsaspp_wgrad_desc& d, hipStream_t s) {
     // one round of resident blocks (one per CU): the fewest atomic epilogues
     int ksplit = d.ksplit > 0 ? d.ksplit : n_cu / tiles;
     if (ksplit < 1) ksplit = 1;
-    int64_t chunk = (M64 + ksplit - 1) / ksplit;
-    chunk = (chunk + 2 * BK - 1) / (2 * BK) * (2 * BK);
-    if (chunk < 4 * BK) chunk = 4 * BK;
-    ksplit = (int)((M64 + chunk - 1) / chunk);
-    // per-lane operand offsets are 32-bit byte offsets from the block's first row
+    // per-lane operand offsets are 32-bit byte offsets from the block's first row (a 64-bit scalar): a pixel range whose
+    // rows span 4 GiB or more is cut into more, shorter ranges
     const int64_t ldmax = d.ldx > d.lddz ? d.ldx : d.lddz;
+    int64_t chunk;
+    for (;;) {
+        chunk = (M64 + ksplit - 1) / ksplit;
+        chunk = (chunk + 2 * BK - 1) / (2 * BK) * (2 * BK);
+        if (chunk < 4 * BK) chunk = 4 * BK;
+        if ((chunk + 2 * BK) * ldmax * 2 < (1ll << 32) || chunk == 4 * BK) break;
+        ksplit *= 2;
+    }
+    ksplit = (int)((M64 + chunk - 1) / chunk);
     if ((chunk + 2 * BK) * ldmax * 2 >= (1ll << 32) || (int64_t)tiles * ksplit >= (1ll << 31)) return -1;
     a.x = reinterpret_cast<const u16*>(d.x);
     a.dz = reinterpret_cast<const u16*>(d.dz);

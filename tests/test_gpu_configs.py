@@ -8,8 +8,9 @@ not depend on size, plus kernels at the far end of their address range.
     2048x4096 the bf16 form is compared with the fp32 form of the same network (2e-2 of the largest logit) so that
     what is computed at the far end of the buffers is checked, not just that nothing faulted;
   * DenseASPP161 (the benchmark network) against the oracle at 128x256;
-  * the streaming 1x1 forward and the grouped slab data gradient on a slab larger than 4 GiB: the rows at the end of
-    the slab must equal what the same kernel computes for those rows alone.
+  * the streaming 1x1 forward, the grouped slab data gradient, the wide-tile data gradient and the wide-tile forward on a
+    slab larger than 4 GiB: the rows at the end of the slab must equal what the same kernel computes for those rows
+    alone, and the wide kernels must be the ones that ran (no change of route at 4 GiB).
 """
 import ctypes
 
@@ -237,24 +238,44 @@ def test_kernels_on_a_slab_past_4GiB():
     assert torch.equal(got, want)
     assert bool((gs.view(M, LD)[M - tail:, CIN:] == 0).all())        # channels past cout untouched
 
-    # ---- single-source slab data gradient with a long K: the 256 x 256-tile kernel addresses the slab by 32-bit byte
-    #      offsets and must leave a slab this large to the 128 x 128 kernel; the tail problem (small offsets) runs on it
+    # ---- single-source slab data gradient with a long K on the 256 x 256 tile: pixel rows are addressed from a 64-bit
+    #      tile base, so the route does not change when the slab passes 4 GiB, and the rows at its end equal what the
+    #      same kernel computes for them alone
     import sys
     lib = sys.modules['semantic_segmentation_amd']._lib
     KW = 256
     dyw = torch.randn(M * KW, device='cuda', generator=g).to(torch.bfloat16)
     ww = (torch.randn(CIN * KW, device='cuda', generator=g) * KW ** -0.5).to(torch.bfloat16)
-    gs.zero_()
-    gs_t.zero_()
-    d1 = dict(_CONV, n_img=n, H=H, W=W, cin=KW, cout=CIN, taps=1, dil=1, x=Ref(dyw), ldx=KW, w=Ref(ww), epi_relu=1,
-              ref=Ref(slab), ldref=LD, e_scale=Ref(es[0]), e_shift=Ref(eh[0]), e_mean=Ref(mean), e_rstd=Ref(rstd),
-              s_acc=Ref(acc[0]), g=Ref(gs), ldg=LD, g_accumulate=0, g_bf16=1)
-    be.call('conv', **d1)
-    assert lib.conv_last_route() == 'dgrad_group'
-    be.call('conv', **dict(d1, H=8, x=Ref(dyw, (M - tail) * KW), ref=Ref(slab, off), g=Ref(gs_t)))
-    assert lib.conv_last_route() == 'dgrad_wide'
+    for accumulate in (0, 1):
+        gs.copy_(slab) if accumulate else gs.zero_()
+        gs_t.copy_(slab[off:]) if accumulate else gs_t.zero_()
+        d1 = dict(_CONV, n_img=n, H=H, W=W, cin=KW, cout=CIN, taps=1, dil=1, x=Ref(dyw), ldx=KW, w=Ref(ww), epi_relu=1,
+                  ref=Ref(slab), ldref=LD, e_scale=Ref(es[0]), e_shift=Ref(eh[0]), e_mean=Ref(mean), e_rstd=Ref(rstd),
+                  s_acc=Ref(acc[0]), g=Ref(gs), ldg=LD, g_accumulate=accumulate, g_bf16=1)
+        be.call('conv', **d1)
+        assert lib.conv_last_route() == 'dgrad_wide'
+        be.call('conv', **dict(d1, H=8, x=Ref(dyw, (M - tail) * KW), ref=Ref(slab, off), g=Ref(gs_t)))
+        assert lib.conv_last_route() == 'dgrad_wide'
+        torch.cuda.synchronize()
+        got = gs.view(M, LD)[M - tail:, :CIN]
+        want = gs_t.view(tail, LD)[:, :CIN]
+        assert torch.isfinite(got.float()).all() and float(want.float().abs().max()) > 0
+        assert torch.equal(got, want)
+
+    # ---- BN-ReLU-1x1 forward with many output channels on the 256 x 256 tile (a transition at this slab size): x rows
+    #      past 2^32 bytes, output rows of a tensor that is itself 2.2 GB
+    COUT = 1056
+    wf = (torch.randn(COUT * CIN, device='cuda', generator=g) * CIN ** -0.5).to(torch.bfloat16)
+    del gs, gs_t, dyw
+    torch.cuda.empty_cache()
+    yw = torch.zeros(M * COUT, dtype=torch.bfloat16, device='cuda')
+    yw_t = torch.zeros(tail * COUT, dtype=torch.bfloat16, device='cuda')
+    fw = dict(_CONV, n_img=n, H=H, W=W, cin=CIN, cout=COUT, taps=1, dil=1, x=Ref(slab), ldx=LD, w=Ref(wf), in_scale=Ref(sc),
+              in_shift=Ref(sh), in_relu=1, y=Ref(yw), ldy=COUT)
+    be.call('conv', **fw)
+    assert lib.conv_last_route() == 'conv_wide'
+    be.call('conv', **dict(fw, H=8, x=Ref(slab, off), y=Ref(yw_t)))
+    assert lib.conv_last_route() == 'conv_wide'
     torch.cuda.synchronize()
-    got = gs.view(M, LD)[M - tail:, :CIN].float()
-    want = gs_t.view(tail, LD)[:, :CIN].float()
-    assert torch.isfinite(got).all() and float(want.abs().max()) > 0
-    assert float((got - want).abs().max()) <= 2e-2 * float(want.abs().max())      # two kernels, one bf16 rounding apart at most
+    assert torch.isfinite(yw.float()).all() and float(yw_t.float().abs().max()) > 0
+    assert torch.equal(yw[(M - tail) * COUT:], yw_t)
