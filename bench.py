@@ -91,11 +91,11 @@ def reference_loop_rate(model, x, labels, steps=3, warmup=1):
     torch.cuda.synchronize()
     dt = (time.time() - t0) / steps
     return dict(value=round(x.shape[0] / dt, 3), unit='img/s', ms_per_step=round(1e3 * dt, 2), batch=x.shape[0], steps=steps,
-                loss=round(float(loss), 5),
+                loss=round(float(loss.detach()), 5),
                 loop='zero_grad; model(x) -> fp32 NCHW logits; CrossEntropyLoss(ignore_index=255); backward(); torch.optim.Adam.step()')
 
 
-def config4_rate(device, H, W, steps=3, warmup=1, reserve=0.12):
+def config4_rate(device, H, W, steps=3, warmup=1, reserve=0.15):
     """BASELINE config 4: DenseASPP201 training at 1024x2048 with the largest per-GPU batch that fits the HBM.  The
     batch is found from the memory one engine of 4 images takes: whole multiples of 8 images that leave `reserve` of the
     device memory free."""
