@@ -5,11 +5,11 @@ compiler-inserted `s_waitcnt vmcnt(0)` inside it.  In a kernel that feeds its op
 hand-counted vmcnt, either of the two inside the K-loop drains the DMA queue once per iteration (a scratch reload is
 waited for with vmcnt(0), because the compiler's own count does not include the DMAs).
 
-    python tools_check_isa.py [source.hip ...]        (default: the DMA-fed kernels)
+    python tools/check_isa.py [source.hip ...]        (default: the DMA-fed kernels)
 """
 import os, re, subprocess, sys, tempfile
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'semantic-segmentation_amd', 'csrc')
 DEFAULT = ['dgrad_wide.hip', 'conv_wide.hip', 'wgrad_wide.hip', 'wgrad3x3_strip.hip', 'dgrad_group.hip', 'wgrad_group.hip', 'conv1x1_stream.hip', 'dgrad3x3_fused.hip', 'conv3x3_halo.hip']
 

@@ -2,7 +2,7 @@
 """Micro-benchmark of the MFMA kernels on the dominant DenseASPP161 layer shapes (diagnostic)."""
 import argparse, os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import denseASPP
 from semantic_segmentation_amd.backend import HipBackend
 from semantic_segmentation_amd.engine import Ref
@@ -102,7 +102,7 @@ for name, (kind, f) in cases.items():
     fl = 2.0*M*f['cout']*f['taps']*(sum([f['cin']] + [f['cin%d' % k] for k in range(1, f['n_src'])]) if kind == 'wgrad' and f.get('n_src', 0) > 1 else f['cin']*max(1, f.get('n_src', 0)))
     print('%-14s %9.1f us  %7.1f TFLOP/s' % (name, us, fl/us/1e6), flush=True)
 
-# ---- do two different kernels overlap when they run on two streams?  (python tools_conv_bench.py --only overlap)
+# ---- do two different kernels overlap when they run on two streams?  (python tools/conv_bench.py --only overlap)
 if a.only == 'overlap':
     from semantic_segmentation_amd.engine import OpList
     kind, f = cases['fwd1x1']; f = dict(f); f['stat_acc'] = None

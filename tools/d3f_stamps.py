@@ -3,7 +3,7 @@
 import ctypes, os, sys
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import denseASPP  # noqa: F401
 from semantic_segmentation_amd import _lib
 from semantic_segmentation_amd.backend import HipBackend

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Batch-sharded inference throughput (no collective) of any cfg on one MI355X: forward + fused x8 upsample/arg-max.
 
-    python tools_infer_bench.py --model MobileNetDenseASPP --batch 16                      # BASELINE config 2
-    python tools_infer_bench.py --model DenseASPP169 --batch 4 --height 2048 --width 4096  # config 5 (halo stress)
+    python tools/infer_bench.py --model MobileNetDenseASPP --batch 16                      # BASELINE config 2
+    python tools/infer_bench.py --model DenseASPP169 --batch 4 --height 2048 --width 4096  # config 5 (halo stress)
 
 Prints one JSON line: images/s, per-op-class HIP-event times with the algorithmic flops / bytes of each class.
 """
@@ -15,7 +15,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 ap = argparse.ArgumentParser()

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, 'tests')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 from e2e_common import make_pair, make_batch, make_dropout_masks, grad_report
 from cfgs import DenseASPP121, DenseASPP161
 import denseASPP

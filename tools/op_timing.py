@@ -3,7 +3,7 @@
 (HIP-event timing around each op; diagnostic)."""
 import argparse, importlib, os, sys
 import torch
-ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import denseASPP
 from semantic_segmentation_amd import profiling
 from bench import synth_batch

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-kernel means of the counters of one rocprofv3 --pmc pass (counter_collection.csv): python tools_pmc_summary.py <csv> [name filter]"""
+"""Per-kernel means of the counters of one rocprofv3 --pmc pass (counter_collection.csv): python tools/pmc_summary.py <csv> [name filter]"""
 import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 flt = sys.argv[2] if len(sys.argv) > 2 else ''

@@ -6,7 +6,7 @@ reads at 64 bytes, so the read side is doubled before the two are added.  Writes
 {class: {"fetch_kib": .., "write_kib": .., "hbm_bytes_per_launch": .., "launches": ..}}.
 """
 import csv, json, sys, collections
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import denseASPP  # noqa: F401
 from semantic_segmentation_amd import profiling
 

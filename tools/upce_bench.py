@@ -2,7 +2,7 @@
 """Micro-benchmark of the fused bilinear x8 + cross-entropy kernel at the benchmark size (diagnostic)."""
 import argparse, os, sys
 import torch
-ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import denseASPP  # noqa: F401
 from semantic_segmentation_amd.backend import HipBackend
 from semantic_segmentation_amd.engine import OpList, Ref
