@@ -19,7 +19,7 @@
 #endif
 
 #ifndef D3F_STAMP
-#define D3F_STAMP 0   // diagnostic build: wave 0 of every block records the shader clock at its phase boundaries (tools_d3f_stamps.py)
+#define D3F_STAMP 0   // diagnostic build: wave 0 of every block records the shader clock at its phase boundaries (tools/d3f_stamps.py)
 #endif
 #if D3F_STAMP
 __device__ unsigned long long d3f_stamps[4096 * 16];

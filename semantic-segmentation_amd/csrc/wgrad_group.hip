@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_group_kernel(const WGArgs a) {
     //      from an opaque copy of the lane id so that the compiler does not hoist them back out of the K-loop) instead of
     //      being kept in eight registers: with four sources of 192 output channels the accumulators alone take 192, one
     //      accumulator tile went to scratch, and its reload inside the K-loop -- waited for with vmcnt(0) -- drained the DMA
-    //      queue at every stage.  tools_check_isa.py reports scratch accesses and vmcnt(0) waits inside MFMA loops.
+    //      queue at every stage.  tools/check_isa.py reports scratch accesses and vmcnt(0) waits inside MFMA loops.
     const int zch_ok = (a.cout + 7) / 8;              // data chunks that exist in a dz row
     constexpr int ZMIN = Z_INSTR / NW;                   // DMA instructions every wave issues per tile (some issue one more)
     int d_stage = 0, d_k = 0, d_s = 0;                   // DMA cursor; frozen on the last tile once it is reached
