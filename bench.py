@@ -150,7 +150,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
     ap.add_argument('--force-reducer', action='store_true',
                     help='one rank, but run the bucketed all-reduce path of N > 1 (rehearsal)')
     ap.add_argument('--comm-cus', type=int, default=None,

@@ -2,7 +2,7 @@
 # Evidence run for profiles/: bench line, rocprofv3 kernel stats of the same command, two PMC passes (HBM bytes),
 # per-role breakdown, traffic summary.  Usage (on the GPU box): tools/profile_round.sh <tag> [batch]
 tag=${1:-x}
-batch=${2:-16}
+batch=${2:-32}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 o=gpurun_out/prof_$tag
 mkdir -p $o
