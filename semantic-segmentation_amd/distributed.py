@@ -13,9 +13,12 @@ import torch
 import torch.distributed as dist
 
 
-# Compute units left to the collectives while buckets are in flight (of 256 on an MI355X).  RCCL's ring / tree kernels use
-# a few dozen workgroups; 16 CUs = two per XCD cost the persistent kernels 6 % of their grid during the overlapped part of
-# the backward pass only (bench.py --force-reducer --comm-cus N measures a setting on one GPU).
+# Compute units left to the collectives while buckets are in flight (of 256 on an MI355X; DSASPP_COMM_CUS overrides).
+# The persistent kernels hold one 8-wave block with 200-250 registers per wave on every CU, i.e. the whole register file:
+# a collective's workgroups cannot start on such a CU, and if they take CUs first, the persistent kernel's 256 blocks no
+# longer fit in one round and it runs for up to twice its time.  16 CUs = two per XCD.  Measured on one MI355X, where
+# a one-rank all-reduce launches no kernel, so only the cost shows (bench.py --force-reducer --comm-cus N, batch 32):
+# 69.62 img/s with 0, 68.64 with 16 (-1.4 %), 67.31 with 32 (-3.3 %); without the reducer 69.58.
 DEFAULT_COMM_CUS = 16
 
 
@@ -50,7 +53,10 @@ class GradReducer:
         # Compute units the persistent (one block per CU) kernels of the backward pass leave free while collectives are
         # in flight, so that RCCL's reduction kernels have somewhere to run beside them (dsaspp_set_comm_cus).  Only
         # applied when collectives are actually issued; None = DEFAULT_COMM_CUS, 0 = none.
-        self.comm_cus = DEFAULT_COMM_CUS if comm_cus is None else int(comm_cus)
+        if comm_cus is None:
+            import os
+            comm_cus = int(os.environ.get('DSASPP_COMM_CUS', DEFAULT_COMM_CUS))
+        self.comm_cus = int(comm_cus)
         if broadcast:
             broadcast_model(model, 0, group)
         gflat = model._gflat
