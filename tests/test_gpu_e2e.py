@@ -305,3 +305,54 @@ def test_fused_and_separate_gradient_readout_agree():
     # would show there.
     assert per['features.denseblock4.denselayer16'] < 1e-4, per
     assert rel < 0.1 and cos > 0.995, (rel, cos, worst, yard, per)
+
+
+@pytest.mark.parametrize('n_class', [2, 7, 21, 32])
+def test_other_class_counts_end_to_end(n_class):
+    """DenseASPP(model_cfg, n_class): eval logits, the fused arg-max, and a training step (loss, classifier and ASPP
+    gradients, loss.backward() through model(x)) against the oracle built with the same class count -- the fused loss
+    runs its range-checked instantiations (padding classes) for every count other than 19."""
+    import denseASPP
+    from oracle.dense_aspp_ref import DenseASPPRef
+    torch.manual_seed(0)
+    ref = DenseASPPRef(TINY_CFG, n_class=n_class)
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.3, 0.3)
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    mod = denseASPP.DenseASPP(TINY_CFG, n_class, 8)
+    mod.load_state_dict(ref.state_dict())
+    x, labels = make_batch(2, 64, 96, n_class=n_class)
+    ref.eval()
+    mod = mod.cuda().eval()
+    with torch.no_grad():
+        yr = ref(x)
+        ym = mod(x.cuda()).cpu()
+        am = mod.predict(x.cuda()).cpu()
+    assert ym.shape == yr.shape == (2, n_class, 64, 96)
+    assert _logit_err(yr, ym) < 2e-2
+    assert int(am.max()) < n_class and torch.equal(am, ym.argmax(1))
+    masks = make_dropout_masks(ref, 2, torch.Generator().manual_seed(5))
+    loss_r, g_ref = oracle_train(ref, x, labels, masks)
+    mod.train()
+    loss_g = mod.train_step(x.cuda(), labels.cuda(), dropout_masks={k: v.cuda() for k, v in masks.items()})
+    torch.cuda.synchronize()
+    assert abs(float(loss_g) - float(loss_r)) < 2e-3 * abs(float(loss_r)), (float(loss_g), float(loss_r))
+    g = {n: p.grad.cpu().clone() for n, p in mod.named_parameters()}
+
+    def group(prefix):
+        num = sum(float((g_ref[k] - g[k]).pow(2).sum()) for k in g_ref if k.startswith(prefix))
+        return (num / sum(float(g_ref[k].pow(2).sum()) for k in g_ref if k.startswith(prefix))) ** 0.5
+
+    assert g['classification.1.weight'].shape == (n_class, mod.spec.C_aspp, 1, 1)
+    assert group('classification') < BF16_HEAD_TOL and group('ASPP_') < 2 * BF16_HEAD_TOL, (group('classification'), group('ASPP_'))
+    # the reference's loop: full-resolution logits -> torch's CrossEntropyLoss -> backward
+    mod.load_state_dict(ref.state_dict())
+    mod.spec.dropout0 = mod.spec.dropout1 = 0.0
+    mod._engines.clear()
+    out = mod(x.cuda())
+    loss2 = F.cross_entropy(out, labels.cuda(), ignore_index=255)
+    loss2.backward()
+    assert torch.isfinite(loss2) and all(torch.isfinite(p.grad).all() for p in mod.parameters())
