@@ -410,6 +410,23 @@ int dsaspp_dwconv3x3_wgrad(const dsaspp_dwbwd_desc* d, dsaspp_stream_t stream);
  * dsaspp_conv_wgrad with cin = ldcol (uses dsaspp_im2col_desc; ldcol >= 32, a multiple of 8). */
 int dsaspp_stem3_im2col(const dsaspp_im2col_desc* d, dsaspp_stream_t stream);
 
+/* Adjoint of the two stem im2col forms: the gradient with respect to the network input,
+ *   dx[n][ci][hi][wi] (fp32 NCHW) = sum over output positions (ho, wo) and taps (ky, kx) with 2*ho - pad + ky == hi and
+ *   2*wo - pad + kx == wi of dcol[(n*Ho + ho)*Wo + wo][(ky*ks + kx)*3 + ci],
+ * ks = 7 (pad 3: conv0 of the DenseNet trunks) or 3 (pad 1: the MobileNetV2 stem), Ho = H/2, Wo = W/2.  With the column
+ * gradient dcol = dy . W0 (a 1x1 dsaspp_conv_fwd over the stem's output gradient) this is what autograd delivers to an image
+ * tensor that requires grad when loss.backward() runs (reference graph_seg_main.py:237-239).  Each input pixel gathers its at
+ * most 4 x 4 (2 x 2) contributions in a fixed order: no atomics.  accumulate != 0 adds to dx. */
+typedef struct dsaspp_col2im_desc {
+    int32_t n_img, H, W;      /* image size (even) */
+    int32_t ks;               /* 7 or 3 */
+    const void* dcol; int32_t ldcol;   /* bf16 (fp32 when dtype == 1) [N*Ho*Wo][ldcol], ldcol >= ks*ks*3 */
+    float* dx;                /* NCHW fp32, 3 channels */
+    int32_t accumulate;
+    int32_t dtype;
+} dsaspp_col2im_desc;
+int dsaspp_stem_col2im(const dsaspp_col2im_desc* d, dsaspp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Bilinear x8 upsample (align_corners=False) fused with softmax cross-entropy
  * (replaces nn.Upsample(scale_factor=8, mode='bilinear') + CrossEntropyLoss(ignore_index)
@@ -563,7 +580,8 @@ enum {
     DSASPP_OP_AVGPOOL_BWD, DSASPP_OP_IM2COL, DSASPP_OP_MAXPOOL_FWD, DSASPP_OP_MAXPOOL_BWD,
     DSASPP_OP_UPCE, DSASPP_OP_CE_FINALIZE, DSASPP_OP_UP_FWD, DSASPP_OP_UP_BWD, DSASPP_OP_UP_ARGMAX,
     DSASPP_OP_MEMSET, DSASPP_OP_COPY2D, DSASPP_OP_COPY2D_BF16, DSASPP_OP_STEM3, DSASPP_OP_DWCONV,
-    DSASPP_OP_UP2_FWD, DSASPP_OP_UP2_BWD, DSASPP_OP_DW_BWD_DATA, DSASPP_OP_DW_WGRAD, DSASPP_OP_STEM3_COL
+    DSASPP_OP_UP2_FWD, DSASPP_OP_UP2_BWD, DSASPP_OP_DW_BWD_DATA, DSASPP_OP_DW_WGRAD, DSASPP_OP_STEM3_COL,
+    DSASPP_OP_COL2IM
 };
 dsaspp_program* dsaspp_program_create(void);
 void dsaspp_program_destroy(dsaspp_program* p);

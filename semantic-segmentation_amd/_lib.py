@@ -90,6 +90,7 @@ conf_desc = STRUCTS['dsaspp_conf_desc']
 prep_desc = STRUCTS['dsaspp_prep_desc']
 up2_desc = STRUCTS['dsaspp_up2_desc']
 dwbwd_desc = STRUCTS['dsaspp_dwbwd_desc']
+col2im_desc = STRUCTS['dsaspp_col2im_desc']
 
 # op name -> (program op code, descriptor struct, direct entry point)
 OPS = {
@@ -120,6 +121,7 @@ OPS = {
     'dw_bwd_data': (ENUMS['DSASPP_OP_DW_BWD_DATA'], dwbwd_desc, 'dsaspp_dwconv3x3_bwd_data'),
     'dw_wgrad': (ENUMS['DSASPP_OP_DW_WGRAD'], dwbwd_desc, 'dsaspp_dwconv3x3_wgrad'),
     'stem3_col': (ENUMS['DSASPP_OP_STEM3_COL'], im2col_desc, 'dsaspp_stem3_im2col'),
+    'col2im': (ENUMS['DSASPP_OP_COL2IM'], col2im_desc, 'dsaspp_stem_col2im'),
     # direct calls only (not recordable in a program)
     'confusion': (None, conf_desc, 'dsaspp_upsample8_confusion'),
     'preprocess': (None, prep_desc, 'dsaspp_preprocess'),

@@ -364,6 +364,48 @@ __global__ __launch_bounds__(256) void im2col_kernel(const dsaspp_im2col_desc d,
     }
 }
 
+// ---------------------------------------------------------------- adjoint of the stem im2col (input gradient)
+// One thread per input pixel and all three channels: the taps whose parity matches gather from at most 4 x 4 (ks 7) or
+// 2 x 2 (ks 3) output positions, three consecutive column entries each, in a fixed order.
+__device__ __forceinline__ float col_ld(const u16* p) { return bf_lo((uint32_t)*p); }
+__device__ __forceinline__ float col_ld(const float* p) { return *p; }
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(const dsaspp_col2im_desc d, const int pad) {
+    const int H = d.H, W = d.W, Ho = H / 2, Wo = W / 2, ks = d.ks;
+    const int64_t total = (int64_t)d.n_img * H * W;
+    const T* col = reinterpret_cast<const T*>(d.dcol);
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int wi = (int)(idx % W);
+        const int64_t t = idx / W;
+        const int hi = (int)(t % H);
+        const int n = (int)(t / H);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int ky = (hi + pad) & 1; ky < ks; ky += 2) {
+            const int h2 = hi + pad - ky;
+            if (h2 < 0 || (h2 >> 1) >= Ho) continue;
+            for (int kx = (wi + pad) & 1; kx < ks; kx += 2) {
+                const int w2 = wi + pad - kx;
+                if (w2 < 0 || (w2 >> 1) >= Wo) continue;
+                const T* p = col + (((int64_t)n * Ho + (h2 >> 1)) * Wo + (w2 >> 1)) * d.ldcol + (ky * ks + kx) * 3;
+                a0 += col_ld(p);
+                a1 += col_ld(p + 1);
+                a2 += col_ld(p + 2);
+            }
+        }
+        const int64_t plane = (int64_t)H * W;
+        float* o = d.dx + (int64_t)n * 3 * plane + (int64_t)hi * W + wi;
+        if (d.accumulate) {
+            o[0] += a0;
+            o[plane] += a1;
+            o[2 * plane] += a2;
+        } else {
+            o[0] = a0;
+            o[plane] = a1;
+            o[2 * plane] = a2;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- BN+ReLU -> maxpool 3x3 stride 2 pad 1
 template <int CGB>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const dsaspp_maxpool_desc d) {
@@ -602,6 +644,21 @@ extern "C" int dsaspp_stem_im2col(const dsaspp_im2col_desc* d, dsaspp_stream_t s
     DS_REQUIRE(blocks < (1ll << 31), "stem_im2col: too many output row segments (%lld)", (long long)blocks);
     hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d, wtiles);
     DS_LAUNCH_CHECK("stem_im2col");
+    return 0;
+}
+
+extern "C" int dsaspp_stem_col2im(const dsaspp_col2im_desc* d, dsaspp_stream_t stream) {
+    DS_REQUIRE(d && d->n_img > 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0, "stem_col2im: H and W must be even");
+    DS_REQUIRE(d->ks == 7 || d->ks == 3, "stem_col2im: ks must be 7 or 3 (got %d)", d->ks);
+    DS_REQUIRE(d->dcol && d->dx && d->ldcol >= d->ks * d->ks * 3, "stem_col2im: ldcol must be at least ks*ks*3 (got %d)", d->ldcol);
+    DS_REQUIRE(d->dtype == 0 || d->dtype == 1, "stem_col2im: dtype must be 0 (bf16) or 1 (fp32)");
+    const int64_t total = (int64_t)d->n_img * d->H * d->W;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    const int pad = d->ks == 7 ? 3 : 1;
+    if (d->dtype == 1) hipLaunchKernelGGL(col2im_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d, pad);
+    else hipLaunchKernelGGL(col2im_kernel<u16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d, pad);
+    DS_LAUNCH_CHECK("stem_col2im");
     return 0;
 }
 

@@ -89,6 +89,7 @@ union AnyDesc {
     dsaspp_dw_desc dw;
     dsaspp_up2_desc up2;
     dsaspp_dwbwd_desc dwb;
+    dsaspp_col2im_desc c2i;
 };
 struct Op {
     int32_t kind;
@@ -129,6 +130,7 @@ size_t desc_size(int32_t op) {
         case DSASPP_OP_DW_BWD_DATA:
         case DSASPP_OP_DW_WGRAD: return sizeof(dsaspp_dwbwd_desc);
         case DSASPP_OP_STEM3_COL: return sizeof(dsaspp_im2col_desc);
+        case DSASPP_OP_COL2IM: return sizeof(dsaspp_col2im_desc);
         default: return 0;
     }
 }
@@ -291,6 +293,7 @@ extern "C" int dsaspp_program_run(dsaspp_program* p, int32_t first, int32_t last
             case DSASPP_OP_DW_BWD_DATA: rc = dsaspp_dwconv3x3_bwd_data(&o.d.dwb, s); break;
             case DSASPP_OP_DW_WGRAD: rc = dsaspp_dwconv3x3_wgrad(&o.d.dwb, s); break;
             case DSASPP_OP_STEM3_COL: rc = dsaspp_stem3_im2col(&o.d.im2col, s); break;
+            case DSASPP_OP_COL2IM: rc = dsaspp_stem_col2im(&o.d.c2i, s); break;
             default: rc = dsaspp_set_error("program_run: unknown op %d at %d", o.kind, i);
         }
         if (timed) {

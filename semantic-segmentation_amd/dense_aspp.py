@@ -97,7 +97,8 @@ class _LogitsFn(torch.autograd.Function):
         g = model._gflat.clone()
         model._gflat.copy_(held)
         grads = [model.arena.view(g, n) for n in model._param_names]
-        return (None, None) + tuple(grads)
+        gx = eng.input_gradient().clone() if ctx.needs_input_grad[1] else None
+        return (None, gx) + tuple(grads)
 
 
 class DenseASPP(nn.Module):
@@ -465,6 +466,15 @@ class DenseASPP(nn.Module):
         if g0 is None or g0.data_ptr() != self._gflat.data_ptr() + 4 * self.arena.by_name[self._param_names[0]].off:
             self.bind_grads()
         return eng.loss
+
+    def input_gradient(self, x):
+        """Gradient of the loss of the most recent train_step (or of the backward pass just run through model(x)) with
+        respect to the image batch x: N x 3 x H x W fp32.  x only selects the engine (its shape)."""
+        B, _, H, W = x.shape
+        eng = self._engines.get((B, H, W, True))
+        if eng is None or eng._bwd is None:
+            raise RuntimeError('input_gradient: no training step has run for a batch of shape %s' % (tuple(x.shape),))
+        return eng.input_gradient().clone()
 
     def conv_macs(self, height, width):
         return self.spec.conv_macs(height, width)

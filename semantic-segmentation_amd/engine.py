@@ -40,7 +40,7 @@ class Ref:
 
 # ops whose descriptor carries the activation storage type (include/dsaspp.h: `dtype`)
 _DTYPE_OPS = frozenset(('conv', 'bn_act', 'avgpool_fwd', 'im2col', 'maxpool_fwd', 'stem3', 'dwconv', 'wgrad', 'grad_extract',
-                        'bn_bwd_apply', 'avgpool_bwd', 'maxpool_bwd'))
+                        'bn_bwd_apply', 'avgpool_bwd', 'maxpool_bwd', 'col2im'))
 
 
 class OpList(list):
@@ -268,6 +268,7 @@ class Engine:
         self._up_fwd = None
         self._up_bwd = None
         self._argmax = None
+        self._input_grad = None
 
     def _alloc_mobilenet(self, zeros, dt, training):
         """Trunk buffers of the MobileNetV2 variant.  Inference: two block in/out tensors (ping-pong) and the
@@ -965,6 +966,41 @@ class Engine:
                loss=None, dlogits_bf16=None if self.dtype_code else _r(self.dlogits16), lddb=S.CLS_PAD,
                dbias=self.PG('classification.1.bias'))
         return ops
+
+    # ------------------------------------------------------------------ gradient with respect to the input image
+    def build_input_grad(self):
+        """dx (fp32 NCHW) from the stem's output gradient, which the backward program leaves in place: the column gradient
+        dcol = dy . W0 as a 1x1 convolution into the im2col buffer, then the adjoint of the im2col."""
+        assert self.training
+        sp, B = self.spec, self.B
+        if self.mobilenet:
+            ks, kpad, dy, col = 3, S.STEM3_KPAD, self.tmp_a, self.col3
+        else:
+            ks, kpad, dy, col = 7, S.STEM_KPAD, self.tmp_c, self.col
+        cs = sp.c_stem
+        self.dx = self._zeros(B * 3 * self.H * self.W)
+        self.w0t = self._zeros(kpad * cs, self.act_dtype)          # [k][cs]: W0 transposed, rows past ks*ks*3 zero
+        ops = OpList(self.dtype_code)
+        d = dict(self._conv_defaults)
+        d.update(n_img=B, H=self.H0, W=self.W0, cin=cs, cout=kpad, taps=1, dil=1, x=_r(dy), ldx=cs, w=_r(self.w0t), y=_r(col), ldy=kpad)
+        ops.op('conv', **d)
+        ops.op('col2im', n_img=B, H=self.H, W=self.W, ks=ks, dcol=_r(col), ldcol=kpad, dx=_r(self.dx), accumulate=0)
+        return ops
+
+    def input_gradient(self):
+        """Run the input-gradient program (after a backward pass of this engine); returns the N x 3 x H x W fp32 tensor it
+        owns."""
+        if self._input_grad is None:
+            self._input_grad = self.backend.compile(self.build_input_grad())
+        sp = self.spec
+        name = (sp.stem_prefix + '.0.weight') if self.mobilenet else 'features.conv0.weight'
+        ks = 3 if self.mobilenet else 7
+        w = self.arena.view(self.model._flat, name)                 # [cs, 3, ks, ks] view of the fp32 master weight
+        k = ks * ks * 3
+        wt = w.permute(2, 3, 1, 0).reshape(k, sp.c_stem)            # rows (ky, kx, ci): the im2col column order
+        self.w0t.view(-1, sp.c_stem)[:k].copy_(wt)                  # rounds to the activation storage type
+        self._input_grad.run()
+        return self.dx.view(self.B, 3, self.H, self.W)
 
     # ------------------------------------------------------------------ running
     def programs(self):

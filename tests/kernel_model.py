@@ -297,6 +297,21 @@ def op_im2col(f):
     out[:, :147] = cols.to(bf16)
 
 
+def op_col2im(f):
+    n, H, W, ks = f['n_img'], f['H'], f['W'], f['ks']
+    pad = 3 if ks == 7 else 1
+    L = (H // 2) * (W // 2)
+    k = ks * ks * 3
+    dcol = _view(f['dcol'], n * L, k, f['ldcol']).to(torch.float32)          # (ky, kx) major, ci minor
+    cols = dcol.view(n, L, ks * ks, 3).permute(0, 3, 2, 1).reshape(n, k, L)   # unfold's (ci, ky, kx) rows
+    dx = F.fold(cols, (H, W), ks, padding=pad, stride=2)
+    out = torch.as_strided(f['dx'].t, (n, 3, H, W), (3 * H * W, H * W, W, 1), f['dx'].off)
+    if f['accumulate']:
+        out.add_(dx)
+    else:
+        out.copy_(dx)
+
+
 def op_stem3(f):
     n, H, W, cout = f['n_img'], f['H'], f['W'], f['cout']
     x = torch.as_strided(f['x'].t, (n, 3, H, W), (3 * H * W, H * W, W, 1), f['x'].off)
@@ -542,7 +557,7 @@ OPS = {
     'maxpool_fwd': op_maxpool_fwd, 'maxpool_bwd': op_maxpool_bwd, 'upce': op_upce, 'ce_finalize': op_ce_finalize,
     'up_fwd': op_up_fwd, 'up_bwd': op_up_bwd, 'up_argmax': op_up_argmax, 'memset': op_memset, 'copy2d': op_copy2d,
     'stem3': op_stem3, 'dwconv': op_dwconv, 'up2_fwd': op_up2_fwd, 'up2_bwd': op_up2_bwd,
-    'dw_bwd_data': op_dw_bwd_data, 'dw_wgrad': op_dw_wgrad, 'stem3_col': op_stem3_col,
+    'dw_bwd_data': op_dw_bwd_data, 'dw_wgrad': op_dw_wgrad, 'stem3_col': op_stem3_col, 'col2im': op_col2im,
 }
 
 

@@ -7,6 +7,7 @@ With bf16 storage (what the HIP kernels do) the logits must stay within the 2e-2
 """
 import pytest
 import torch
+import torch.nn.functional as F
 
 import kernel_model
 from e2e_common import TINY_CFG, grad_report, make_batch, make_dropout_masks, make_pair, oracle_train
@@ -273,3 +274,38 @@ def test_autograd_backward_keeps_arena_gradients(fp32_model):
     torch.nn.functional.cross_entropy(mod(x), labels, ignore_index=255).backward()
     g2 = mod._gflat.clone()
     assert float((g_sum - (g1 + g2)).abs().max()) <= 1e-5 * float(g_sum.abs().max())
+
+
+def test_input_gradient_fp32(fp32_model):
+    """The gradient with respect to the image (the stem's data gradient): what autograd delivers to an image tensor that
+    requires grad when the reference's loop runs loss.backward(), and what model.input_gradient returns after the fused
+    train_step -- both against the oracle."""
+    ref, mod = make_pair(TINY_CFG)
+    mod.set_backend(kernel_model.ModelBackend())
+    x, labels = make_batch(2, 32, 48)
+    masks = make_dropout_masks(ref, 2, torch.Generator().manual_seed(5))
+    ref.train()
+    xr = x.clone().requires_grad_(True)
+    F.cross_entropy(ref(xr, masks), labels, ignore_index=255).backward()
+    want = xr.grad
+    assert float(want.abs().max()) > 0
+    mod.train()
+    mod.train_step(x, labels, dropout_masks=masks)
+    got = mod.input_gradient(x)
+    assert got.shape == x.shape
+    assert float((got - want).norm() / want.norm()) < 1e-3
+    # through autograd: the same engine state, dropout masks pinned
+    mod.load_state_dict(ref.state_dict())
+    eng = mod.engine(2, 32, 48, True)
+    orig = eng.draw_dropout
+    eng.draw_dropout = lambda generator=None, masks=None: orig(masks=_masks)
+    _masks = masks
+    xm = x.clone().requires_grad_(True)
+    F.cross_entropy(mod(xm), labels, ignore_index=255).backward()
+    assert xm.grad is not None and xm.grad.shape == x.shape
+    # the oracle's running statistics moved in its forward pass; train-mode gradients do not depend on them
+    assert float((xm.grad - want).norm() / want.norm()) < 1e-3
+    # an image that does not require grad costs nothing and gets nothing
+    x2 = x.clone()
+    F.cross_entropy(mod(x2), labels, ignore_index=255).backward()
+    assert x2.grad is None

@@ -194,3 +194,38 @@ def test_bf16_default_gradients_against_the_fp32_form():
     # default path that one can train on is taken away from initialisation, where norm5's backward no longer cancels
     # nearly all of its input: tests/test_gpu_trajectory.py::test_gradients_away_from_initialisation (cos > 0.99).
     assert cos > 0.58 and rel < 0.92, (rel, cos, worst)
+
+
+def test_input_gradient_on_gpu():
+    """Gradient with respect to the image batch (reference loop with an image that requires grad, graph_seg_main.py:237-239):
+    fp32 form of the kernels against the oracle; the bf16 default against the fp32 form at the head of the tolerance the
+    parameter gradients of this configuration have (the image gradient sits at the far end of the backward chain)."""
+    import torch.nn.functional as F
+    from e2e_common import make_dropout_masks
+    ref, mod = make_pair(TINY_CFG)
+    x, labels = make_batch(2, 64, 96)
+    masks = make_dropout_masks(ref, 2, torch.Generator().manual_seed(5))
+    ref.train()
+    xr = x.clone().requires_grad_(True)
+    F.cross_entropy(ref(xr, masks), labels, ignore_index=255).backward()
+    want = xr.grad
+    gm = {k: v.cuda() for k, v in masks.items()}
+    mod = mod.cuda().train().set_compute_dtype(torch.float32)
+    mod.train_step(x.cuda(), labels.cuda(), dropout_masks=gm)
+    g32 = mod.input_gradient(x).cpu()
+    rel32 = float((g32 - want).norm() / want.norm())
+    mod.load_state_dict(ref.state_dict())
+    mod.set_compute_dtype(torch.bfloat16)
+    mod.train_step(x.cuda(), labels.cuda(), dropout_masks=gm)
+    g16 = mod.input_gradient(x).cpu()
+    rel16 = float((g16 - want).norm() / want.norm())
+    cos16 = float((g16 * want).sum() / (g16.norm() * want.norm()))
+    print('input gradient, tiny cfg 2x64x96: fp32 form vs oracle %.2e; bf16 vs oracle rel-L2 %.3f cos %.4f' % (rel32, rel16, cos16))
+    assert rel32 < 1e-3
+    assert torch.isfinite(g16).all() and rel16 < 0.8 and cos16 > 0.7
+    # through autograd, as the reference's loop would see it
+    mod.load_state_dict(ref.state_dict())
+    xm = x.cuda().requires_grad_(True)
+    F.cross_entropy(mod(xm), labels.cuda(), ignore_index=255).backward()
+    assert xm.grad is not None and xm.grad.shape == xm.shape and torch.isfinite(xm.grad).all()
+    assert float(xm.grad.abs().max()) > 0

@@ -679,3 +679,18 @@ def test_upsample_ce_live_label_outside_the_classes(nc):
     got = dev['dlogits'].cpu().view(M, ldl)
     assert float((got[:, :nc] - want_g).abs().max()) < 1e-4 * float(want_g.abs().max())
     assert bool((got[:, nc:] == 0).all())
+
+
+@pytest.mark.parametrize('n,H,W,ks,ld,dtype,acc', [(2, 16, 24, 7, 160, 0, 0), (1, 10, 6, 7, 152, 0, 1), (3, 34, 18, 3, 32, 0, 0),
+                                                   (1, 2, 2, 7, 160, 0, 0), (2, 12, 20, 7, 160, 1, 0), (1, 8, 8, 3, 40, 1, 1)])
+def test_stem_col2im(n, H, W, ks, ld, dtype, acc):
+    """Adjoint of the stem im2col (the gradient with respect to the network input): both kernel sizes, both storage
+    types of the column gradient, overwrite and accumulate, an image smaller than the kernel."""
+    gen = torch.Generator().manual_seed(H * W + ks)
+    L = (H // 2) * (W // 2)
+    dcol = torch.randn(n * L * ld, generator=gen)
+    f = dict(n_img=n, H=H, W=W, ks=ks, dcol=Ref(dcol if dtype else bf(dcol)), ldcol=ld,
+             dx=Ref(torch.randn(n * 3 * H * W, generator=gen)), accumulate=acc, dtype=dtype)
+    out = run_both('col2im', f)
+    assert float(out['dx'][0].abs().max()) > 0
+    close(out['dx'][0], out['dx'][1], 1e-5, 'col2im.dx')
