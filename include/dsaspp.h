@@ -326,6 +326,30 @@ typedef struct dsaspp_im2col_desc {
 } dsaspp_im2col_desc;
 int dsaspp_stem_im2col(const dsaspp_im2col_desc* d, dsaspp_stream_t stream);
 
+/* The same stem without a column matrix in memory (bf16 storage): a block builds the column tile of one output-row
+ * segment in LDS from the input rows it draws from.  dsaspp_stem7_fwd replaces dsaspp_stem_im2col + the 1x1 dsaspp_conv_fwd
+ * over its rows (conv0 of model(image), reference graph_seg_main.py:237): y = bf16(col . w^T) with the batch-statistics sums
+ * of the rounded values in stat_acc.  dsaspp_stem7_wgrad replaces dsaspp_bn_bwd_apply + dsaspp_conv_wgrad of the same layer
+ * (the conv0 part of loss.backward(), graph_seg_main.py:239): dw[q][k] += sum over pixels of dy[p][q] * col[p][k] with
+ * dy = bf16(coefA*dr + coefB*yref + coefC) formed on the fly, k < 147; the blocks' partial sums pass through the workspace
+ * ws (dsaspp_stem7_wgrad_workspace_floats(cout) floats) and are added in a fixed order: no atomics. */
+typedef struct dsaspp_stem7_desc {
+    int32_t n_img, H, W;      /* input image size (even); outputs at Ho = H/2, Wo = W/2 */
+    const float* x;           /* NCHW fp32, 3 channels */
+    int32_t cout;             /* 64 or 96 */
+    const void* w; int32_t ldw;           /* fwd: bf16 [cout][ldw], columns (ky, kx, ci), ldw >= 160, columns >= 147 zero */
+    void* y; int32_t ldy;                 /* fwd: bf16 [N*Ho*Wo][ldy] */
+    float* stat_acc;                      /* fwd: [R][2*cout] or NULL */
+    const void* dr; int32_t lddr; int32_t dr_f32;     /* wgrad: masked gradient entering norm0's backward, bf16 or fp32 */
+    const void* yref; int32_t ldyref;     /* wgrad: the forward output y */
+    const float* coefA; const float* coefB; const float* coefC;   /* wgrad: [cout] each (dsaspp_bn_bwd_finalize, mode 0) */
+    float* dw; int32_t lddw;              /* wgrad: fp32 [cout][lddw], lddw >= 147, accumulated */
+    float* ws; int64_t ws_floats;         /* wgrad: workspace */
+} dsaspp_stem7_desc;
+int dsaspp_stem7_fwd(const dsaspp_stem7_desc* d, dsaspp_stream_t stream);
+int dsaspp_stem7_wgrad(const dsaspp_stem7_desc* d, dsaspp_stream_t stream);
+int64_t dsaspp_stem7_wgrad_workspace_floats(int32_t cout);
+
 typedef struct dsaspp_maxpool_desc {
     int32_t n_img, H, W, C;   /* input (conv0 output) geometry; output ceil(H/2) x ceil(W/2), H, W even */
     const void* x; int32_t ldx;       /* raw conv0 output bf16 */
@@ -581,7 +605,7 @@ enum {
     DSASPP_OP_UPCE, DSASPP_OP_CE_FINALIZE, DSASPP_OP_UP_FWD, DSASPP_OP_UP_BWD, DSASPP_OP_UP_ARGMAX,
     DSASPP_OP_MEMSET, DSASPP_OP_COPY2D, DSASPP_OP_COPY2D_BF16, DSASPP_OP_STEM3, DSASPP_OP_DWCONV,
     DSASPP_OP_UP2_FWD, DSASPP_OP_UP2_BWD, DSASPP_OP_DW_BWD_DATA, DSASPP_OP_DW_WGRAD, DSASPP_OP_STEM3_COL,
-    DSASPP_OP_COL2IM
+    DSASPP_OP_COL2IM, DSASPP_OP_STEM7_FWD, DSASPP_OP_STEM7_WGRAD
 };
 dsaspp_program* dsaspp_program_create(void);
 void dsaspp_program_destroy(dsaspp_program* p);

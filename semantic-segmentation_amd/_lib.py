@@ -91,6 +91,7 @@ prep_desc = STRUCTS['dsaspp_prep_desc']
 up2_desc = STRUCTS['dsaspp_up2_desc']
 dwbwd_desc = STRUCTS['dsaspp_dwbwd_desc']
 col2im_desc = STRUCTS['dsaspp_col2im_desc']
+stem7_desc = STRUCTS['dsaspp_stem7_desc']
 
 # op name -> (program op code, descriptor struct, direct entry point)
 OPS = {
@@ -122,6 +123,8 @@ OPS = {
     'dw_wgrad': (ENUMS['DSASPP_OP_DW_WGRAD'], dwbwd_desc, 'dsaspp_dwconv3x3_wgrad'),
     'stem3_col': (ENUMS['DSASPP_OP_STEM3_COL'], im2col_desc, 'dsaspp_stem3_im2col'),
     'col2im': (ENUMS['DSASPP_OP_COL2IM'], col2im_desc, 'dsaspp_stem_col2im'),
+    'stem7_fwd': (ENUMS['DSASPP_OP_STEM7_FWD'], stem7_desc, 'dsaspp_stem7_fwd'),
+    'stem7_wgrad': (ENUMS['DSASPP_OP_STEM7_WGRAD'], stem7_desc, 'dsaspp_stem7_wgrad'),
     # direct calls only (not recordable in a program)
     'confusion': (None, conf_desc, 'dsaspp_upsample8_confusion'),
     'preprocess': (None, prep_desc, 'dsaspp_preprocess'),
@@ -165,6 +168,8 @@ def load():
                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
     lib.dsaspp_copy2d_f32_bf16.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                            ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    lib.dsaspp_stem7_wgrad_workspace_floats.argtypes = [ctypes.c_int32]
+    lib.dsaspp_stem7_wgrad_workspace_floats.restype = ctypes.c_int64
     lib.dsaspp_set_comm_cus.argtypes = [ctypes.c_int32]
     lib.dsaspp_set_comm_cus.restype = ctypes.c_int
     lib.dsaspp_get_comm_cus.restype = ctypes.c_int

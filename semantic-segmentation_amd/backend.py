@@ -60,6 +60,10 @@ class HipBackend:
         self.lib = _lib.load()
         self.act_dtype = act_dtype
 
+    @staticmethod
+    def has_op(kind):
+        return kind in _lib.OPS
+
     def compile(self, oplist):
         h = self.lib.dsaspp_program_create()
         if not h:

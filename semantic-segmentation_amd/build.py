@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, 'csrc')
 ROOT = os.path.dirname(HERE)
 INCLUDE = os.path.join(ROOT, 'include')
 LIB = os.path.join(HERE, 'libdsaspp.so')
-SOURCES = ['conv_mfma.hip', 'dgrad_group.hip', 'dgrad_wide.hip', 'conv_wide.hip', 'wgrad_wide.hip', 'wgrad3x3_strip.hip', 'conv3x3_halo.hip', 'dgrad3x3_fused.hip', 'conv1x1_stream.hip', 'wgrad_mfma.hip', 'wgrad_group.hip', 'elementwise.hip', 'loss.hip', 'optim.hip', 'mobilenet.hip', 'mobilenet_bwd.hip', 'fp32_path.hip', 'eval_ops.hip', 'program.hip']
+SOURCES = ['conv_mfma.hip', 'dgrad_group.hip', 'dgrad_wide.hip', 'conv_wide.hip', 'wgrad_wide.hip', 'wgrad3x3_strip.hip', 'conv3x3_halo.hip', 'dgrad3x3_fused.hip', 'conv1x1_stream.hip', 'wgrad_mfma.hip', 'wgrad_group.hip', 'elementwise.hip', 'loss.hip', 'optim.hip', 'mobilenet.hip', 'mobilenet_bwd.hip', 'stem_fused.hip', 'fp32_path.hip', 'eval_ops.hip', 'program.hip']
 
 
 def _hipcc():

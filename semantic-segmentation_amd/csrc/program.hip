@@ -90,6 +90,7 @@ union AnyDesc {
     dsaspp_up2_desc up2;
     dsaspp_dwbwd_desc dwb;
     dsaspp_col2im_desc c2i;
+    dsaspp_stem7_desc stem7;
 };
 struct Op {
     int32_t kind;
@@ -131,6 +132,8 @@ size_t desc_size(int32_t op) {
         case DSASPP_OP_DW_WGRAD: return sizeof(dsaspp_dwbwd_desc);
         case DSASPP_OP_STEM3_COL: return sizeof(dsaspp_im2col_desc);
         case DSASPP_OP_COL2IM: return sizeof(dsaspp_col2im_desc);
+        case DSASPP_OP_STEM7_FWD:
+        case DSASPP_OP_STEM7_WGRAD: return sizeof(dsaspp_stem7_desc);
         default: return 0;
     }
 }
@@ -294,6 +297,8 @@ extern "C" int dsaspp_program_run(dsaspp_program* p, int32_t first, int32_t last
             case DSASPP_OP_DW_WGRAD: rc = dsaspp_dwconv3x3_wgrad(&o.d.dwb, s); break;
             case DSASPP_OP_STEM3_COL: rc = dsaspp_stem3_im2col(&o.d.im2col, s); break;
             case DSASPP_OP_COL2IM: rc = dsaspp_stem_col2im(&o.d.c2i, s); break;
+            case DSASPP_OP_STEM7_FWD: rc = dsaspp_stem7_fwd(&o.d.stem7, s); break;
+            case DSASPP_OP_STEM7_WGRAD: rc = dsaspp_stem7_wgrad(&o.d.stem7, s); break;
             default: rc = dsaspp_set_error("program_run: unknown op %d at %d", o.kind, i);
         }
         if (timed) {

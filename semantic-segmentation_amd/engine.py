@@ -124,6 +124,7 @@ class Engine:
 
         # ---- activations
         self.mobilenet = sp.kind == 'mobilenet'
+        self.fused_stem = False
         self.x_in = zeros(B * 3 * height * width)
         self.slabs = []
         self.aslab = Slab(self, self.M2, sp.C_aspp, self.H2, self.W2, training)
@@ -131,7 +132,10 @@ class Engine:
         if self.mobilenet:
             self._alloc_mobilenet(zeros, bf16, training)
         else:
-            self.col = zeros(self.M0 * S.STEM_KPAD, bf16)
+            # conv0 without a column matrix in memory (dsaspp_stem7_fwd / dsaspp_stem7_wgrad): bf16 storage, 64 or 96 channels
+            self.fused_stem = (bool(getattr(model, 'fused_stem', True)) and self.dtype_code == 0 and sp.c_stem in (64, 96)
+                               and hasattr(backend, 'has_op') and backend.has_op('stem7_fwd'))
+            self.col = zeros(8 if self.fused_stem else self.M0 * S.STEM_KPAD, bf16)
             self.c0out = zeros(self.M0 * sp.c_stem, bf16)
             for blk in sp.blocks:
                 M, H, W = self.geo[blk.res]
@@ -353,6 +357,14 @@ class Engine:
             f.update(scale=None, shift=None)
         ops.op('bn_finalize', **f)
 
+    def _stem7(self, **kw):
+        """Descriptor fields of the fused stem ops (forward and weight gradient share one struct)."""
+        d = dict(n_img=self.B, H=self.H, W=self.W, x=_r(self.x_in), cout=self.spec.c_stem, w=None, ldw=0, y=None, ldy=0,
+                 stat_acc=None, dr=None, lddr=0, dr_f32=0, yref=None, ldyref=0, coefA=None, coefB=None, coefC=None, dw=None,
+                 lddw=0, ws=None, ws_floats=0)
+        d.update(kw)
+        return d
+
     # ------------------------------------------------------------------ forward
     def build_forward(self):
         sp, tr = self.spec, self.training
@@ -378,9 +390,13 @@ class Engine:
 
         # ---- stem: im2col + GEMM, norm0 statistics, BN-ReLU-maxpool into slab 1
         cs = sp.c_stem
-        ops.op('im2col', n_img=B, H=self.H, W=self.W, x=_r(self.x_in), col=_r(self.col), ldcol=S.STEM_KPAD)
-        C(n_img=B, H=self.H0, W=self.W0, cin=S.STEM_KPAD, cout=cs, taps=1, dil=1, x=_r(self.col), ldx=S.STEM_KPAD,
-          w=_r(self.model._w0_16), y=_r(self.c0out), ldy=cs, stat_acc=_r(self.acc['features.norm0']) if tr else None)
+        if self.fused_stem:
+            ops.op('stem7_fwd', **self._stem7(w=_r(self.model._w0_16), ldw=S.STEM_KPAD, y=_r(self.c0out), ldy=cs,
+                                              stat_acc=_r(self.acc['features.norm0']) if tr else None))
+        else:
+            ops.op('im2col', n_img=B, H=self.H, W=self.W, x=_r(self.x_in), col=_r(self.col), ldcol=S.STEM_KPAD)
+            C(n_img=B, H=self.H0, W=self.W0, cin=S.STEM_KPAD, cout=cs, taps=1, dil=1, x=_r(self.col), ldx=S.STEM_KPAD,
+              w=_r(self.model._w0_16), y=_r(self.c0out), ldy=cs, stat_acc=_r(self.acc['features.norm0']) if tr else None)
         self._bn_finalize(ops, 'features.norm0', cs, acc=_r(self.acc['features.norm0']) if tr else None, acc_c0=0,
                           acc_cn=cs if tr else 0, count=self.M0)
         s1 = self.slabs[0]
@@ -838,6 +854,16 @@ class Engine:
                stat_acc=None, dy=_r(dz), lddy=cs, dr=_r(dr), lddr=cs, dr_f32=self.dr_f32, mean=self.bnt(n0, 'mean', cs),
                rstd=self.bnt(n0, 'rstd', cs), s_acc=_r(self.acc['features.norm0']))
         bn_bwd(n0, cs, 'features.norm0', self.M0, 0)
+        if self.fused_stem:
+            # BatchNorm-backward apply of norm0 and conv0's weight gradient in one kernel, column tiles rebuilt from the image
+            if getattr(self, 'stem_ws', None) is None:
+                n_ws = int(self.backend.lib.dsaspp_stem7_wgrad_workspace_floats(cs)) if hasattr(self.backend, 'lib') else 8
+                self.stem_ws = self._zeros(n_ws)
+            ops.op('stem7_wgrad', **self._stem7(dr=_r(dr), lddr=cs, dr_f32=self.dr_f32, yref=_r(self.c0out), ldyref=cs,
+                                                coefA=_r(self.coef, 0), coefB=_r(self.coef, cs), coefC=_r(self.coef, 2 * cs),
+                                                dw=self.PG('features.conv0.weight'), lddw=S.STEM_K, ws=_r(self.stem_ws),
+                                                ws_floats=self.stem_ws.numel()))
+            return ops
         bn_apply(cs, self.M0, dr, self.c0out, dy1)
         zero(self.dw0pad)
         WG(n_img=B, H=self.H0, W=self.W0, cin=S.STEM_KPAD, cout=cs, taps=1, dil=1, x=_r(self.col), ldx=S.STEM_KPAD,
@@ -973,14 +999,20 @@ class Engine:
         dcol = dy . W0 as a 1x1 convolution into the im2col buffer, then the adjoint of the im2col."""
         assert self.training
         sp, B = self.spec, self.B
+        cs = sp.c_stem
+        ops = OpList(self.dtype_code)
         if self.mobilenet:
             ks, kpad, dy, col = 3, S.STEM3_KPAD, self.tmp_a, self.col3
+        elif self.fused_stem:
+            # the fused weight gradient formed dy on the fly: form it here, into a column buffer of its own
+            ks, kpad, dy = 7, S.STEM_KPAD, self.tmp_c
+            col = self._zeros(self.M0 * kpad, self.act_dtype)
+            ops.op('bn_bwd_apply', M=self.M0, C=cs, dr=_r(self.tmp_b), lddr=cs, dr_f32=self.dr_f32, y=_r(self.c0out), ldy=cs,
+                   coefA=_r(self.coef, 0), coefB=_r(self.coef, cs), coefC=_r(self.coef, 2 * cs), dy=_r(dy), lddy=cs, colsum=None)
         else:
             ks, kpad, dy, col = 7, S.STEM_KPAD, self.tmp_c, self.col
-        cs = sp.c_stem
         self.dx = self._zeros(B * 3 * self.H * self.W)
         self.w0t = self._zeros(kpad * cs, self.act_dtype)          # [k][cs]: W0 transposed, rows past ks*ks*3 zero
-        ops = OpList(self.dtype_code)
         d = dict(self._conv_defaults)
         d.update(n_img=B, H=self.H0, W=self.W0, cin=cs, cout=kpad, taps=1, dil=1, x=_r(dy), ldx=cs, w=_r(self.w0t), y=_r(col), ldy=kpad)
         ops.op('conv', **d)

@@ -297,6 +297,37 @@ def op_im2col(f):
     out[:, :147] = cols.to(bf16)
 
 
+def _stem7_cols(f):
+    n, H, W = f['n_img'], f['H'], f['W']
+    x = torch.as_strided(f['x'].t, (n, 3, H, W), (3 * H * W, H * W, W, 1), f['x'].off)
+    cols = F.unfold(x, 7, padding=3, stride=2)
+    L = cols.shape[-1]
+    return _rbf(cols.view(n, 3, 49, L).permute(0, 3, 2, 1).reshape(n * L, 147))     # (ky, kx) major, ci minor; bf16 values
+
+
+def op_stem7_fwd(f):
+    cout = f['cout']
+    cols = _stem7_cols(f)
+    w = _view(f['w'], cout, 147, f['ldw']).to(torch.float32)
+    y = (cols @ w.t()).to(bf16)
+    _view(f['y'], cols.shape[0], cout, f['ldy']).copy_(y)
+    if f['stat_acc'] is not None:
+        acc = _view(f['stat_acc'], R, 2 * cout, 2 * cout)
+        yf = y.to(torch.float32)
+        acc[0, :cout] += yf.sum(0)
+        acc[0, cout:] += (yf * yf).sum(0)
+
+
+def op_stem7_wgrad(f):
+    cout = f['cout']
+    cols = _stem7_cols(f)
+    M = cols.shape[0]
+    dr = _view(f['dr'], M, cout, f['lddr']).to(torch.float32)
+    y = _view(f['yref'], M, cout, f['ldyref']).to(torch.float32)
+    dy = _rbf(_vec(f['coefA'], cout) * dr + (_vec(f['coefB'], cout) * y + _vec(f['coefC'], cout)))
+    _view(f['dw'], cout, 147, f['lddw']).add_(dy.t() @ cols)
+
+
 def op_col2im(f):
     n, H, W, ks = f['n_img'], f['H'], f['W'], f['ks']
     pad = 3 if ks == 7 else 1
@@ -557,7 +588,7 @@ OPS = {
     'maxpool_fwd': op_maxpool_fwd, 'maxpool_bwd': op_maxpool_bwd, 'upce': op_upce, 'ce_finalize': op_ce_finalize,
     'up_fwd': op_up_fwd, 'up_bwd': op_up_bwd, 'up_argmax': op_up_argmax, 'memset': op_memset, 'copy2d': op_copy2d,
     'stem3': op_stem3, 'dwconv': op_dwconv, 'up2_fwd': op_up2_fwd, 'up2_bwd': op_up2_bwd,
-    'dw_bwd_data': op_dw_bwd_data, 'dw_wgrad': op_dw_wgrad, 'stem3_col': op_stem3_col, 'col2im': op_col2im,
+    'dw_bwd_data': op_dw_bwd_data, 'dw_wgrad': op_dw_wgrad, 'stem3_col': op_stem3_col, 'col2im': op_col2im, 'stem7_fwd': op_stem7_fwd, 'stem7_wgrad': op_stem7_wgrad,
 }
 
 
@@ -586,6 +617,10 @@ class ModelBackend:
     @property
     def act_dtype(self):
         return bf16
+
+    @staticmethod
+    def has_op(kind):
+        return kind in OPS
 
     def compile(self, oplist):
         return ModelProgram(oplist)

@@ -5,6 +5,8 @@ gradient and the BatchNorm running statistics to fp32 accuracy -- this pins the 
 "concatenate in front" ASPP ordering and the single-pass BatchNorm-backward correction scheme.
 With bf16 storage (what the HIP kernels do) the logits must stay within the 2e-2 budget.
 """
+import copy
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -309,3 +311,29 @@ def test_input_gradient_fp32(fp32_model):
     x2 = x.clone()
     F.cross_entropy(mod(x2), labels, ignore_index=255).backward()
     assert x2.grad is None
+
+
+def test_fused_stem_plan_matches_the_im2col_plan():
+    """conv0 without a column matrix (stem7_fwd / stem7_wgrad) against im2col + GEMM + bn_bwd_apply + weight gradient:
+    the same arithmetic with the same rounding points, so the bf16 kernel model must give the same loss and gradients."""
+    cfg = dict(TINY_CFG)
+    cfg.update(num_init_features=64, growth_rate=32, bn_size=1)      # 64 stem channels; block widths stay multiples of 8
+    ref, mod = make_pair(cfg)
+    x, labels = make_batch(2, 32, 48)
+    masks = make_dropout_masks(ref, 2, torch.Generator().manual_seed(5))
+    out = {}
+    for fused in (True, False):
+        m = copy.deepcopy(mod)
+        m.fused_stem = fused
+        m.set_backend(kernel_model.ModelBackend())
+        m.train()
+        loss = float(m.train_step(x, labels, dropout_masks=masks))
+        eng = m.engine(2, 32, 48, True)
+        assert eng.fused_stem == fused
+        kinds = {k for k, _ in eng._fwd.ops} | {k for k, _ in eng._bwd.ops}
+        assert ('stem7_fwd' in kinds and 'stem7_wgrad' in kinds) == fused and ('im2col' in kinds) == (not fused)
+        out[fused] = (loss, {n: p.grad.clone() for n, p in m.named_parameters()}, m.input_gradient(x))
+    assert abs(out[True][0] - out[False][0]) < 1e-6
+    for n, g in out[False][1].items():
+        assert torch.allclose(g, out[True][1][n], rtol=1e-4, atol=1e-7), n
+    assert torch.allclose(out[True][2], out[False][2], rtol=1e-4, atol=1e-8)

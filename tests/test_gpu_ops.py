@@ -694,3 +694,50 @@ def test_stem_col2im(n, H, W, ks, ld, dtype, acc):
     out = run_both('col2im', f)
     assert float(out['dx'][0].abs().max()) > 0
     close(out['dx'][0], out['dx'][1], 1e-5, 'col2im.dx')
+
+
+STEM7_CASES = [
+    # n, H, W, cout: output rows shorter than one 64-pixel segment, exactly one, two with a tail, many segments
+    (2, 10, 36, 96), (1, 16, 128, 64), (1, 12, 200, 96), (3, 34, 18, 64), (1, 6, 520, 96), (1, 2, 2, 64),
+]
+
+
+@pytest.mark.parametrize('case', range(len(STEM7_CASES)))
+def test_stem7_fwd(case, monkeypatch):
+    """conv0 without a column matrix: output and batch-statistics sums against the kernel model (im2col + GEMM)."""
+    n, H, W, cout = STEM7_CASES[case]
+    if case == 2:
+        monkeypatch.setenv('DSASPP_DGG_GRID', '8')      # (the persistent grid is bounded by the segment count anyway)
+    gen = torch.Generator().manual_seed(50 + case)
+    M = n * (H // 2) * (W // 2)
+    ldy = cout + 8 * (case % 2)
+    w = torch.zeros(cout, 160)
+    w[:, :147] = torch.randn(cout, 147, generator=gen) * 147 ** -0.5
+    f = dict(n_img=n, H=H, W=W, x=Ref(torch.randn(n * 3 * H * W, generator=gen)), cout=cout, w=Ref(bf(w.reshape(-1))), ldw=160,
+             y=Ref(torch.zeros(M * ldy, dtype=torch.bfloat16)), ldy=ldy, stat_acc=Ref(torch.zeros(R * 2 * cout)), dr=None, lddr=0,
+             dr_f32=0, yref=None, ldyref=0, coefA=None, coefB=None, coefC=None, dw=None, lddw=0, ws=None, ws_floats=0)
+    out = run_both('stem7_fwd', f)
+    close(out['y'][0], out['y'][1], 1e-2, 'stem7_fwd.y')
+    close(out['stat_acc'][0].view(R, -1).sum(0), out['stat_acc'][1].view(R, -1).sum(0), 2e-3, 'stem7_fwd.stat_acc')
+    if ldy > cout:
+        assert bool((out['y'][1].view(M, ldy)[:, cout:] == 0).all())          # row padding untouched
+
+
+@pytest.mark.parametrize('case', range(len(STEM7_CASES)))
+@pytest.mark.parametrize('dr_f32', [0, 1])
+def test_stem7_wgrad(case, dr_f32):
+    """conv0's weight gradient with norm0's BatchNorm-backward apply formed on the fly, accumulated into dw."""
+    from semantic_segmentation_amd import _lib
+    n, H, W, cout = STEM7_CASES[case]
+    gen = torch.Generator().manual_seed(80 + case)
+    M = n * (H // 2) * (W // 2)
+    dr = torch.randn(M * cout, generator=gen)
+    n_ws = int(_lib.load().dsaspp_stem7_wgrad_workspace_floats(cout))
+    f = dict(n_img=n, H=H, W=W, x=Ref(torch.randn(n * 3 * H * W, generator=gen)), cout=cout, w=None, ldw=0, y=None, ldy=0, stat_acc=None,
+             dr=Ref(dr if dr_f32 else bf(dr)), lddr=cout, dr_f32=dr_f32, yref=Ref(bf(torch.randn(M * cout, generator=gen))), ldyref=cout,
+             coefA=Ref(torch.rand(cout, generator=gen) + 0.5), coefB=Ref(torch.randn(cout, generator=gen) * 0.1),
+             coefC=Ref(torch.randn(cout, generator=gen) * 0.1), dw=Ref(torch.randn(cout * 147, generator=gen)), lddw=147,
+             ws=Ref(torch.full((n_ws,), 7.0)), ws_floats=n_ws)
+    out = run_both('stem7_wgrad', f)
+    assert float(out['dw'][0].abs().max()) > 0
+    close(out['dw'][0], out['dw'][1], 2e-4, 'stem7_wgrad.dw')
