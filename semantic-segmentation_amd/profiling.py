@@ -14,7 +14,8 @@ CLASSES = ['untimed',
            'wgrad_kernel<64,192,1,4>', 'wgrad_kernel<192,128,4,2>', 'wgrad_kernel<128,128,2,4>',
            'upce_kernel<19>', 'wgrad_kernel<48,192,1,4>', 'wgrad_kernel<32,192,1,4>', 'dgrad_group_kernel', 'conv3x3_halo_kernel',
            'conv1x1_stream_kernel<192>', 'conv1x1_stream_kernel<128>', 'wgrad_group_kernel', 'dgrad3x3_fused_kernel', 'dgrad_wide_kernel', 'conv_wide_kernel<256>',
-           'wgrad_wide_kernel', 'wgrad3x3_strip_kernel', 'conv_wide_kernel<192>', 'conv_wide_kernel<128>']
+           'wgrad_wide_kernel', 'wgrad3x3_strip_kernel', 'conv_wide_kernel<192>', 'conv_wide_kernel<128>', 'stem7_fwd_kernel',
+           'stem7_wgrad_kernel']
 
 
 def kernel_class(kind, f):
@@ -96,6 +97,10 @@ def kernel_class(kind, f):
         return 8
     if kind == 'upce':
         return 9
+    if kind == 'stem7_fwd':
+        return 24
+    if kind == 'stem7_wgrad':
+        return 25
     return 0
 
 
@@ -125,6 +130,12 @@ def work(kind, f):
         else:
             by += (4.0 if f.get('y_f32') else esz) * M * f['cout']
         return 2.0 * M * f['cout'] * f['taps'] * f['cin'] * n, by
+    if kind in ('stem7_fwd', 'stem7_wgrad'):
+        M0 = f['n_img'] * (f['H'] // 2) * (f['W'] // 2)
+        img = 4.0 * 3 * f['n_img'] * f['H'] * f['W']
+        # forward: image in, bf16 output out; weight gradient: image, masked gradient and forward output in
+        by = img + 2.0 * M0 * f['cout'] * (1 if kind == 'stem7_fwd' else 2)
+        return 2.0 * M0 * f['cout'] * 147, by
     if kind == 'upce':
         m = f['n_img'] * f['h'] * f['w']
         # fp32 low-res logits read (n_class), int64 labels read, fp32 low-res gradient written
