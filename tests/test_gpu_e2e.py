@@ -76,7 +76,7 @@ def _copy_engine_state(src, dst):
         cp(src.y1[k], dst.y1[k])
     for k in src.bn:
         cp(src.bn[k], dst.bn[k])
-    for k in ('col', 'c0out', 't1tmp', 't4out', 'logits', 'argmax0', 'dropmask', 'labels'):
+    for k in ('x_in', 'col', 'c0out', 't1tmp', 't4out', 'logits', 'argmax0', 'dropmask', 'labels'):
         cp(getattr(src, k), getattr(dst, k))
 
 
