@@ -71,9 +71,9 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None):
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
     for src, p in procs:
-        out, _ = p.communicate()
-        if out.strip() and (verbose or p.returncode != 0):
-            print(out)
+        log, _ = p.communicate()
+        if log.strip() and (verbose or p.returncode != 0):
+            print(log)
         if p.returncode != 0:
             failed = True
             print('FAILED: %s' % src, file=sys.stderr)

@@ -104,6 +104,21 @@ def test_conv(case):
     check_conv(conv_fields(seed=case, **CONV_CASES[case]))
 
 
+@pytest.mark.parametrize('n,H,W,cin,cout,dil,grid', [
+    (3, 40, 70, 192, 48, 2, 8),        # 45 tiles on 8 blocks: 5 or 6 tiles per block, six 32-channel items per tile
+    (2, 24, 100, 128, 32, 4, 8),       # four items per tile: the register ring of three wraps inside a tile
+    (5, 17, 33, 64, 64, 1, 16),        # 30 tiles on 16 blocks: one or two tiles per block, two items per tile
+    (2, 30, 64, 192, 48, 3, 8),        # dilation 3; an item count per block that is no multiple of the ring depth
+    (1, 9, 40, 320, 40, 4, 8)])        # 4 tiles on 4 blocks (fewer tiles than blocks), ten items per tile
+def test_conv3x3_halo_walks_tiles(n, H, W, cin, cout, dil, grid, monkeypatch):
+    """The halo-patch 3x3 forward kernel is persistent: a block walks several tiles, its loads run ahead across tile
+    boundaries, and the statistics of all its tiles leave in one set of atomics."""
+    monkeypatch.setenv('DSASPP_DGG_GRID', str(grid))
+    check_conv(conv_fields(n=n, H=H, W=W, cin=cin, cout=cout, taps=9, dil=dil, ldy=cout + 48, yoff=16, stats=True,
+                           seed=1200 + cin + dil))
+    assert pkg._lib.conv_last_route() == 'conv3x3_halo'
+
+
 def multi_source_fields(n_src, n=2, H=10, W=12, cin=192, cout=200, sld=264, g_bf16=False, g_acc=True, stats=True):
     f = conv_fields(n=n, H=H, W=W, cin=cin, cout=cout, taps=1, dil=1, scale=False, relu=False, epi_relu=True,
                     e_scale=True, s_acc=True, g=True, g_acc=g_acc, g_bf16=g_bf16, ldy=cout + 64, yoff=8, seed=40 + n_src)
