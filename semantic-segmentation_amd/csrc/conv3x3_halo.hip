@@ -72,7 +72,7 @@ __device__ __forceinline__ void wait_vm() {
 
 // 64 lanes x 16 B from the lanes' global addresses to LDS [lds_base, +1024), lane-linear
 __device__ __forceinline__ void dma16(const uint32_t lds_base, const unsigned char* p) {
-    if (C3H_ABL == 4 || C3H_ABL == 45) asm volatile("" : : "s"(lds_base), "v"(p) : "memory");
+    if (C3H_ABL == 4) asm volatile("" : : "s"(lds_base), "v"(p) : "memory");
     else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_base), "v"(p) : "memory");
 }
 
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const dsaspp_conv_d
             unsigned char* p = smem + buf * PBYTES + pw * 1024 + lane * 16;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                if (C3H_ABL == 5 || C3H_ABL == 45) continue;
+                if (C3H_ABL == 5) continue;
                 float f[8];
                 unpack8(*reinterpret_cast<const uint4*>(p + i * 4096), f);
 #pragma unroll
@@ -330,9 +330,6 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const dsaspp_conv_d
             }
         };
 
-#ifdef C3H_PRIO
-        __builtin_amdgcn_s_setprio(C3H_PRIO);
-#endif
         lds_barrier();                                  // item 0 is staged
         int pb = 0;
         for (int q = 0; q < nitems; ++q) {
