@@ -103,11 +103,16 @@ __global__ __launch_bounds__(NT, 2) void dgrad3x3_fused_kernel(const dsaspp_conv
             wv[u] = *reinterpret_cast<const u32x4*>(wg + (ok ? (size_t)row * (9 * CIN) + ph * G::KPH + c * 8 : 0));
         }
     };
+    // Output channel q sits in LDS row tile(q) * 16 + r(q) with q = 32 P + 8 gq + 4 h + e  ->  tile 2 P + h, row 4 gq + e: a lane of
+    // the accumulator layout (rows 4 g .. 4 g + 3 of every tile) then holds channels 32 P + 8 g .. + 7 in tiles 2 P and 2 P + 1 --
+    // sixteen consecutive bytes per pixel, so the epilogue loads and stores 16-byte pieces (64 consecutive bytes per pixel and
+    // instruction) instead of 8-byte ones.
     auto store_w = [&]() {
 #pragma unroll
         for (int u = 0; u < NWL; ++u) {
             const int idx = tid + u * NT;
-            const int row = idx / G::WCPR, c = idx - row * G::WCPR;
+            const int q = idx / G::WCPR, c = idx - q * G::WCPR;
+            const int row = ((q >> 5) * 2 + ((q >> 2) & 1)) * 16 + ((q >> 3) & 3) * 4 + (q & 3);
             if (idx < COUT * G::WCPR) *reinterpret_cast<u32x4*>(wlds + row * G::WROWB + c * 16) = wv[u];
         }
     };
@@ -194,7 +199,18 @@ __global__ __launch_bounds__(NT, 2) void dgrad3x3_fused_kernel(const dsaspp_conv
         pok[j] = oy < H && ox < W;
         poff[j] = pok[j] ? ((int64_t)n * H + oy) * W + ox : 0;
     }
-    uint2 rr[MQ][MP];
+    constexpr int NPR = MQ / 2;                          // pairs of channel tiles
+    static_assert(MQ % 2 == 0 && COUT % 32 == 0, "channel tiles are paired");
+    uint4 rr[NPR][MP];
+    auto load_ref = [&](const int p0, const int p1) {
+#pragma unroll
+        for (int pr = 0; pr < NPR; ++pr)
+#pragma unroll
+            for (int j = 0; j < MP; ++j)
+                if (pr >= p0 && pr < p1)
+                    rr[pr][j] = D3F_ABL == 3 ? make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u)
+                                             : *reinterpret_cast<const uint4*>(rg + poff[j] * d.ldref + pr * 32 + g * 8);
+    };
 
     // Fragments are read in groups (the step's two pixel fragments, then WGN filter fragments at a time), one group
     // ahead of the MFMAs that use them: explicit double buffer, order pinned with scheduling barriers, so that a wave
@@ -210,12 +226,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad3x3_fused_kernel(const dsaspp_conv
         __syncthreads();                                // filter rows (and, the first time, the patch) visible
         STAMP(4 + 3 * ph);
         if (ph < 2) load_w(ph + 1);                     // in flight during this phase's MFMAs
-        if (ph == 2) {
-#pragma unroll
-            for (int i = 0; i < MQ / 2; ++i)
-#pragma unroll
-                for (int j = 0; j < MP; ++j) rr[i][j] = D3F_ABL == 3 ? make_uint2(0x3f803f80u, 0x3f803f80u) : *reinterpret_cast<const uint2*>(rg + poff[j] * d.ldref + i * 16 + g * 4);
-        }
+        if (ph == 2) load_ref(0, NPR / 2);
         bf16x8 afb[2][MP], wfb[2][WGN];
         auto read_group = [&](const int t) {
             const int s = t / NG, gi = t - s * NG;
@@ -257,10 +268,7 @@ __global__ __launch_bounds__(NT, 2) void dgrad3x3_fused_kernel(const dsaspp_conv
 
     // ---- epilogue: lane holds output channels q = i*16 + g*4 .. +3 of pixels (ty0 + wave, tx0 + j*16 + fr)
     u16* yg = reinterpret_cast<u16*>(d.y);
-#pragma unroll
-    for (int i = MQ / 2; i < MQ; ++i)
-#pragma unroll
-        for (int j = 0; j < MP; ++j) rr[i][j] = D3F_ABL == 3 ? make_uint2(0x3f803f80u, 0x3f803f80u) : *reinterpret_cast<const uint2*>(rg + poff[j] * d.ldref + i * 16 + g * 4);
+    load_ref(NPR / 2, NPR);
     // patch and filter rows are dead: the patch becomes the table of sums.  The barrier waits for this wave's LDS
     // operations only; __syncthreads() would also wait for the reference loads just issued
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -272,42 +280,52 @@ __global__ __launch_bounds__(NT, 2) void dgrad3x3_fused_kernel(const dsaspp_conv
     // totals are formed: sum(v * xhat) = rstd * (sum(v * ref) - mean * sum(v)).
     const bool full = ty0 + TH <= H && tx0 + TW <= W;      // every pixel of the patch is inside the image (block-uniform)
 #pragma unroll
-    for (int i = 0; i < MQ; ++i) {
-        const int q = i * 16 + g * 4;
-        const f32x4 es = *reinterpret_cast<const f32x4*>(tab + q), eh = *reinterpret_cast<const f32x4*>(tab + COUT + q);
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int pr = 0; pr < NPR; ++pr) {
+        const int q = pr * 32 + g * 8;                  // this lane's eight channels: tile 2 pr holds the first four, 2 pr + 1 the rest
+        float s1[8], s2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
         // ReLU mask as a number: clamp(2^64 * (ref * scale + shift)) is 1 for every positive pre-activation of at least
         // 2^-64, 0 for zero, negatives and NaN: one packed fma with the clamp modifier per two elements
         constexpr float BIG = 18446744073709551616.f;
-        const f32x2_t scb[2] = {{es[0] * BIG, es[1] * BIG}, {es[2] * BIG, es[3] * BIG}};
-        const f32x2_t shb[2] = {{eh[0] * BIG, eh[1] * BIG}, {eh[2] * BIG, eh[3] * BIG}};
+        f32x2_t scb[4], shb[4];
 #pragma unroll
-        for (int j = 0; j < MP; ++j) {
-            const f32x2_t rf[2] = {{bf_lo(rr[i][j].x), bf_hi(rr[i][j].x)}, {bf_lo(rr[i][j].y), bf_hi(rr[i][j].y)}};
-            float v[4];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f32x2_t m;
-                asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m) : "v"(rf[h]), "v"(scb[h]), "v"(shb[h]));
-#pragma unroll
-                for (int e2 = 0; e2 < 2; ++e2) {
-                    const int e = 2 * h + e2;
-                    v[e] = acc[i][j][e] * m[e2];
-                    if (!full) v[e] = pok[j] ? v[e] : 0.f;      // rows past the image edge were computed from padding
-                    s1[e] += v[e];
-                    s2[e] = fmaf(v[e], rf[h][e2], s2[e]);
-                }
-            }
-            if (pok[j] && (D3F_ABL != 3 || v[0] == 12345.678f)) *reinterpret_cast<uint2*>(yg + poff[j] * d.ldy + q) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 es = *reinterpret_cast<const f32x4*>(tab + q + 4 * h), eh = *reinterpret_cast<const f32x4*>(tab + COUT + q + 4 * h);
+            scb[2 * h] = f32x2_t{es[0] * BIG, es[1] * BIG}; scb[2 * h + 1] = f32x2_t{es[2] * BIG, es[3] * BIG};
+            shb[2 * h] = f32x2_t{eh[0] * BIG, eh[1] * BIG}; shb[2 * h + 1] = f32x2_t{eh[2] * BIG, eh[3] * BIG};
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int j = 0; j < MP; ++j) {
+            const uint32_t rw[4] = {rr[pr][j].x, rr[pr][j].y, rr[pr][j].z, rr[pr][j].w};
+            uint32_t ow[4];
+#pragma unroll
+            for (int h2 = 0; h2 < 4; ++h2) {            // channel pair 2 h2, 2 h2 + 1 of the eight: tile 2 pr + h2 / 2, elements 2 (h2 & 1), + 1
+                const f32x2_t rf = {bf_lo(rw[h2]), bf_hi(rw[h2])};
+                f32x2_t m;
+                asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m) : "v"(rf), "v"(scb[h2]), "v"(shb[h2]));
+                float v[2];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    v[e2] = acc[2 * pr + (h2 >> 1)][j][2 * (h2 & 1) + e2] * m[e2];
+                    if (!full) v[e2] = pok[j] ? v[e2] : 0.f;      // rows past the image edge were computed from padding
+                    s1[2 * h2 + e2] += v[e2];
+                    s2[2 * h2 + e2] = fmaf(v[e2], rf[e2], s2[2 * h2 + e2]);
+                }
+                ow[h2] = pack_bf2(v[0], v[1]);
+            }
+            if (pok[j] && (D3F_ABL != 3 || ow[0] == 0x12345678u)) *reinterpret_cast<uint4*>(yg + poff[j] * d.ldy + q) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
             s1[e] = row16_sum(s1[e]);
             s2[e] = row16_sum(s2[e]);
         }
         if (fr == 0) {                                  // one plain store per total into the wave's own row of the table
             *reinterpret_cast<f32x4*>(sred + q) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+            *reinterpret_cast<f32x4*>(sred + q + 4) = f32x4{s1[4], s1[5], s1[6], s1[7]};
             *reinterpret_cast<f32x4*>(sred + COUT + q) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+            *reinterpret_cast<f32x4*>(sred + COUT + q + 4) = f32x4{s2[4], s2[5], s2[6], s2[7]};
         }
     }
     STAMP(13);
