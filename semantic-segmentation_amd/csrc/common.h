@@ -101,6 +101,25 @@ __device__ __forceinline__ uint4 relu_bf8(uint4 v, uint32_t floor_bits) {
 }
 __device__ __forceinline__ float bf_round(float f) { return __uint_as_float(f2bf_bits(f) << 16); }
 
+// 16-byte global accesses with the non-temporal hint: for tensors that are streamed through once (hundreds of MB
+// against 32 MB of L2 and 256 MB of memory-side cache), so that they do not push out what IS used again -- weights, halos,
+// the rows a neighbouring tile shares.  NT = false gives the plain access (one template for both, chosen per call site).
+// Measured in the training step (batch 32, same box): the BatchNorm-backward apply with hinted loads and stores 448.9 ->
+// 444.7 ms, the other row-wise kernels with hinted loads 450.2 -> 446.8 (hinted stores add nothing there).  NOT for tensors
+// the next kernel reads at once: hinted stores of the convolutions' outputs cost 7 ms, the hint on the grouped data
+// gradient's slab traffic 3 ms.
+typedef uint32_t ds_u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 ld16(const void* p) {
+    if (!NT) return *reinterpret_cast<const uint4*>(p);
+    const ds_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const ds_u32x4*>(p));
+    return uint4{v.x, v.y, v.z, v.w};
+}
+template <bool NT>
+__device__ __forceinline__ void st16(void* p, const uint4 v) {
+    if (!NT) *reinterpret_cast<uint4*>(p) = v;
+    else __builtin_nontemporal_store(ds_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<ds_u32x4*>(p));
+}
 // 8 bf16 (one 16-byte chunk) <-> 8 floats
 __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
     f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);

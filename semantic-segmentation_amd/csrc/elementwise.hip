@@ -4,6 +4,11 @@
 // the block through LDS, then added to one of DS_R replica rows with fp32 atomics.
 #include "common.h"
 
+#ifndef EW_NT
+#define EW_NT 1                  // row-wise kernels: bit 0 loads, bit 1 stores with the non-temporal hint
+#endif
+constexpr bool EWL = (EW_NT & 1) != 0, EWS = (EW_NT & 2) != 0;
+
 namespace {
 
 // ---------------------------------------------------------------- BN finalize (forward)
@@ -97,21 +102,21 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const dsaspp_bnact_desc d) 
     const float lo = d.relu ? 0.f : -3.0e38f, hi = (d.relu == 2) ? 6.f : 3.0e38f;
     if (act) {
         for (int64_t m = (int64_t)blockIdx.y * RB + ry; m < d.M; m += (int64_t)gridDim.y * RB) {
-            const uint4 v = *reinterpret_cast<const uint4*>(xg + m * d.ldx + c);
+            const uint4 v = ld16<EWL>(xg + m * d.ldx + c);
             float f[8];
             unpack8(v, f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
             if (rg) {
                 float r[8];
-                unpack8(*reinterpret_cast<const uint4*>(rg + m * d.ldres + c), r);
+                unpack8(ld16<EWL>(rg + m * d.ldres + c), r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] += r[e];
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(f[e], lo), hi);
             const uint4 o = pack8(f);
-            *reinterpret_cast<uint4*>(yg + m * d.ldy + c) = o;
+            st16<EWS>(yg + m * d.ldy + c, o);
             if (d.stat_acc) {
                 float g[8];
                 unpack8(o, g);
@@ -149,11 +154,11 @@ __global__ __launch_bounds__(256) void grad_extract_kernel(const dsaspp_gradx_de
     if (act) {
         for (int64_t m = (int64_t)blockIdx.y * RB + ry; m < d.M; m += (int64_t)gridDim.y * RB) {
             float v[8];
-            if (d.g_bf16) unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(d.g) + m * d.ldg + c), v);
+            if (d.g_bf16) unpack8(ld16<EWL>(reinterpret_cast<const u16*>(d.g) + m * d.ldg + c), v);
             else load8f(reinterpret_cast<const float*>(d.g) + m * d.ldg + c, v);
             if (d.corr1) {
                 float x[8];
-                unpack8(*reinterpret_cast<const uint4*>(xs + m * d.ldxs + c), x);
+                unpack8(ld16<EWL>(xs + m * d.ldxs + c), x);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] -= k1[e] + ((x[e] - sm[e]) * sr[e]) * k2[e];
             }
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256) void grad_extract_kernel(const dsaspp_gradx_de
                 for (int e = 0; e < 8; ++e) v[e] *= mk[e];
             }
             float y[8];
-            if (d.relu || d.s_acc) unpack8(*reinterpret_cast<const uint4*>(yr + m * d.ldyref + c), y);
+            if (d.relu || d.s_acc) unpack8(ld16<EWL>(yr + m * d.ldyref + c), y);
             if (d.relu) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256) void grad_extract_kernel(const dsaspp_gradx_de
                 }
             }
             if (d.dz_f32) store8f(reinterpret_cast<float*>(d.dz) + m * d.lddz + c, v);
-            else *reinterpret_cast<uint4*>(dz + m * d.lddz + c) = pack8(v);
+            else st16<EWS>(dz + m * d.lddz + c, pack8(v));
             if (d.s_acc) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { part[0][e] += v[e]; part[1][e] += v[e] * ((y[e] - rm[e]) * rr[e]); }
@@ -212,11 +217,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const dsaspp_bnapply_desc
         for (int64_t m = (int64_t)blockIdx.y * RB + ry; m < d.M; m += (int64_t)gridDim.y * RB) {
             float a[8], y[8], o[8];
             if (d.dr_f32) load8f(reinterpret_cast<const float*>(d.dr) + m * d.lddr + c, a);
-            else unpack8(*reinterpret_cast<const uint4*>(dr + m * d.lddr + c), a);
-            unpack8(*reinterpret_cast<const uint4*>(yy + m * d.ldy + c), y);
+            else unpack8(ld16<EWL>(dr + m * d.lddr + c), a);
+            unpack8(ld16<EWL>(yy + m * d.ldy + c), y);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { o[e] = fmaf(A[e], a[e], fmaf(B[e], y[e], Cc[e])); part[0][e] += o[e]; }
-            *reinterpret_cast<uint4*>(dy + m * d.lddy + c) = pack8(o);
+            st16<EWS>(dy + m * d.lddy + c, pack8(o));
         }
     }
     if (d.colsum) block_colsum<CGB, 1>(part, red, d.colsum, d.C, blockIdx.x * CGB, 0, 0);
@@ -233,7 +238,13 @@ __global__ __launch_bounds__(256) void bn_apply_flat_kernel(const dsaspp_bnapply
     load8f(d.coefA + c, A); load8f(d.coefB + c, B); load8f(d.coefC + c, Cc);
     const uint4* yy = reinterpret_cast<const uint4*>(d.y);
     uint4* dy = reinterpret_cast<uint4*>(d.dy);
-    constexpr int U = 4;
+#ifndef BNAF_U
+#define BNAF_U 8
+#endif
+#ifndef BNAF_NT
+#define BNAF_NT 3                // bit 0: loads, bit 1: stores carry the non-temporal hint
+#endif
+    constexpr int U = BNAF_U;
     for (int64_t g = g0; g < nchunks; g += U * stride) {
         float a[U][8];
         uint4 yv[U];
@@ -242,8 +253,8 @@ __global__ __launch_bounds__(256) void bn_apply_flat_kernel(const dsaspp_bnapply
             const int64_t gu = g + u * stride;
             const int64_t gc = gu < nchunks ? gu : g;
             if (DRF32) load8f(reinterpret_cast<const float*>(d.dr) + gc * 8, a[u]);
-            else unpack8(reinterpret_cast<const uint4*>(d.dr)[gc], a[u]);
-            yv[u] = yy[gc];
+            else unpack8(ld16<(BNAF_NT & 1) != 0>(reinterpret_cast<const uint4*>(d.dr) + gc), a[u]);
+            yv[u] = ld16<(BNAF_NT & 1) != 0>(yy + gc);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -252,7 +263,7 @@ __global__ __launch_bounds__(256) void bn_apply_flat_kernel(const dsaspp_bnapply
             unpack8(yv[u], y);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = fmaf(A[e], a[u][e], fmaf(B[e], y[e], Cc[e]));
-            if (gu < nchunks) dy[gu] = pack8(o);
+            if (gu < nchunks) st16<(BNAF_NT & 2) != 0>(dy + gu, pack8(o));
         }
     }
 }
@@ -602,8 +613,11 @@ extern "C" int dsaspp_bn_bwd_apply(const dsaspp_bnapply_desc* d, dsaspp_stream_t
         while (r) { const int t = q % r; q = r; r = t; }
         q = CG / q;
         const int64_t nchunks = d->M * CG;
+#ifndef BNAF_BLOCKS
+#define BNAF_BLOCKS 2048
+#endif
         int64_t blocks = (nchunks + 4 * 256 - 1) / (4 * 256);
-        if (blocks > 2048) blocks = 2048;
+        if (blocks > BNAF_BLOCKS) blocks = BNAF_BLOCKS;
         blocks = (blocks + q - 1) / q * q;
         if (d->dr_f32) hipLaunchKernelGGL(bn_apply_flat_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d, CG, nchunks);
         else hipLaunchKernelGGL(bn_apply_flat_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d, CG, nchunks);
