@@ -535,6 +535,158 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const dsaspp_maxpool_d
     if (d.s_acc) block_colsum<CGB, 2>(part, red, d.s_acc, d.C, blockIdx.x * CGB, 2 * d.C, blockIdx.y % DS_R);
 }
 
+// Flat forms of the two stem max-pool kernels (bf16, fewer than 2^31 (pixel, chunk) pairs): the (pixel, 16-byte chunk) pairs are
+// one long index space and the grid stride is a multiple of the chunks per pixel, so that a thread keeps its channel group
+// (coefficients loaded once, per-thread column sums) and every lane is busy whatever C is -- 96 channels are 12 chunks, the
+// row-block form leaves 4 of 16 lanes idle -- all loads of a pixel issued before the first is used, 32-bit index arithmetic
+// (the row-block forms divide 64-bit pixel indices).  Column sums: per-thread partials, LDS atomics once per thread at the end, one
+// set of global atomics per block.
+template <int NS>
+__device__ __forceinline__ void flat_colsum(const float (&part)[NS][8], float* red /* NS * C floats, zeroed */, float* acc, const int C,
+                                            const int c, const int rep_stride, const int rep) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(red + s * C + c + e, part[s][e]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < NS * C; i += 256) atomicAdd(acc + (size_t)rep * rep_stride + i, red[i]);
+}
+
+__global__ __launch_bounds__(256) void maxpool_fwd_flat_kernel(const dsaspp_maxpool_desc d, const int CG, const uint32_t npairs) {
+    extern __shared__ float red[];
+    const int Ho = d.H / 2, Wo = d.W / 2;
+    const uint32_t g0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u, dm = stride / CG;
+    const int c = (int)(g0 % CG) * 8;
+    float sc[8], sh[8], part[2][8];
+    load8f(d.scale + c, sc); load8f(d.shift + c, sh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { part[0][e] = 0.f; part[1][e] = 0.f; }
+    if (d.stat_acc) {
+        for (int i = threadIdx.x; i < 2 * d.C; i += 256) red[i] = 0.f;
+        __syncthreads();
+    }
+    const u16* xg = reinterpret_cast<const u16*>(d.x);
+    u16* yg = reinterpret_cast<u16*>(d.y);
+    const uint32_t Mo = npairs / CG;
+    for (uint32_t m = g0 / CG; m < Mo; m += dm) {
+        const uint32_t n = m / (uint32_t)(Ho * Wo), rem = m - n * (uint32_t)(Ho * Wo);
+        const int ho = (int)(rem / (uint32_t)Wo), wo = (int)(rem - (uint32_t)ho * Wo);
+        uint4 v[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hi = 2 * ho - 1 + t / 3, wi = 2 * wo - 1 + t % 3;
+            const bool ok = (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
+            v[t] = ld16<false>(xg + (((int64_t)n * d.H + (ok ? hi : 2 * ho)) * d.W + (ok ? wi : 2 * wo)) * d.ldx + c);   // outside: the centre again
+        }
+        float best[8];
+        int arg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -1.f; arg[e] = 0; }   // relu output >= 0 > -1
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hi = 2 * ho - 1 + t / 3, wi = 2 * wo - 1 + t % 3;
+            if ((unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W) {
+                float f[8];
+                unpack8(v[t], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = fmaxf(fmaf(f[e], sc[e], sh[e]), 0.f);
+                    if (x > best[e]) { best[e] = x; arg[e] = t; }
+                }
+            }
+        }
+        const uint4 ov = pack8(best);
+        *reinterpret_cast<uint4*>(yg + (int64_t)m * d.ldy + c) = ov;
+        if (d.argmax) {
+            uint2 a;
+            a.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+            a.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
+            *reinterpret_cast<uint2*>(d.argmax + (int64_t)m * d.C + c) = a;
+        }
+        if (d.stat_acc) {
+            float g[8];
+            unpack8(ov, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { part[0][e] += g[e]; part[1][e] += g[e] * g[e]; }
+        }
+    }
+    if (d.stat_acc) flat_colsum<2>(part, red, d.stat_acc, d.C, c, 2 * d.C, blockIdx.x % DS_R);
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_flat_kernel(const dsaspp_maxpool_desc d, const int CG, const uint32_t npairs) {
+    extern __shared__ float red[];
+    const int Ho = d.H / 2, Wo = d.W / 2;
+    const uint32_t g0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u, dm = stride / CG;
+    const int c = (int)(g0 % CG) * 8;
+    float sc[8], sh[8], mu[8], rs[8], part[2][8];
+    load8f(d.scale + c, sc); load8f(d.shift + c, sh); load8f(d.mean + c, mu); load8f(d.rstd + c, rs);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { part[0][e] = 0.f; part[1][e] = 0.f; }
+    if (d.s_acc) {
+        for (int i = threadIdx.x; i < 2 * d.C; i += 256) red[i] = 0.f;
+        __syncthreads();
+    }
+    const u16* xg = reinterpret_cast<const u16*>(d.x);
+    const u16* dyg = reinterpret_cast<const u16*>(d.dy);
+    u16* drg = reinterpret_cast<u16*>(d.dr);
+    const uint32_t Mi = npairs / CG, HW = (uint32_t)(d.H * d.W);
+    for (uint32_t m = g0 / CG; m < Mi; m += dm) {
+        const uint32_t n = m / HW, rem = m - n * HW;
+        const int h = (int)(rem / (uint32_t)d.W), w = (int)(rem - (uint32_t)h * d.W);
+        // windows (ho, wo) that contain (h, w): 2*ho-1 <= h <= 2*ho+1; a window that does not exist is replaced by one that
+        // does and its contribution dropped, so that the four loads are unconditional
+        const int hoA = h >> 1, hoB = (h + 1) >> 1, woA = w >> 1, woB = (w + 1) >> 1;
+        const uint4 xv = ld16<true>(xg + (int64_t)m * d.ldx + c);
+        uint2 av[4];
+        uint4 dv[4];
+        int tt[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ho = (k & 2) ? hoB : hoA, wo = (k & 1) ? woB : woA;
+            const bool ok = ho < Ho && wo < Wo && !((k & 2) && hoB == hoA) && !((k & 1) && woB == woA);
+            const int hoc = ok ? ho : hoA, woc = ok ? wo : woA;
+            tt[k] = ok ? (h - (2 * ho - 1)) * 3 + (w - (2 * wo - 1)) : 255;
+            const int64_t mo = ((int64_t)n * Ho + hoc) * Wo + woc;
+            av[k] = *reinterpret_cast<const uint2*>(d.argmax + mo * d.C + c);
+            dv[k] = ld16<false>(dyg + mo * d.lddy + c);
+        }
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float dyv[8];
+            unpack8(dv[k], dyv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ae = ((e < 4 ? av[k].x : av[k].y) >> (8 * (e & 3))) & 0xff;
+                if (ae == tt[k]) g[e] += dyv[e];
+            }
+        }
+        float x[8];
+        unpack8(xv, x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float pre = fmaf(x[e], sc[e], sh[e]);
+            if (!(pre > 0.f)) g[e] = 0.f;
+            part[0][e] += g[e];
+            part[1][e] += g[e] * ((x[e] - mu[e]) * rs[e]);
+        }
+        st16<true>(drg + (int64_t)m * d.lddr + c, pack8(g));
+    }
+    if (d.s_acc) flat_colsum<2>(part, red, d.s_acc, d.C, c, 2 * d.C, blockIdx.x % DS_R);
+}
+
+// grid of a flat kernel: a multiple of q = CG / gcd(256, CG) blocks, so that the grid stride is a multiple of CG
+inline int flat_blocks(const int CG, const int64_t npairs, const int per_thread, const int cap) {
+    int q = CG, r = 256;
+    while (r) { const int t = q % r; q = r; r = t; }
+    q = CG / q;
+    int64_t blocks = (npairs + (int64_t)per_thread * 256 - 1) / ((int64_t)per_thread * 256);
+    if (blocks > cap) blocks = cap;
+    return (int)((blocks + q - 1) / q * q);
+}
+
 inline dim3 row_grid(int C, int64_t M, int cgb) {
     const int cg = (C + 7) / 8;
     const int gx = (cg + cgb - 1) / cgb;
@@ -681,6 +833,14 @@ extern "C" int dsaspp_maxpool3s2_fwd(const dsaspp_maxpool_desc* d, dsaspp_stream
     DS_REQUIRE(d->C > 0 && d->C % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->x && d->y && d->scale && d->shift, "maxpool3s2_fwd: bad descriptor");
     if (d->dtype == 1) return dsaspp_f32_maxpool(*d, (hipStream_t)stream);
     const int64_t Mo = (int64_t)d->n_img * (d->H / 2) * (d->W / 2);
+    if (Mo * (d->C / 8) < (1ll << 31) && (int64_t)d->n_img * d->H * d->W < (1ll << 31)) {
+        const int CG = d->C / 8;
+        const int64_t npairs = Mo * CG;
+        hipLaunchKernelGGL(maxpool_fwd_flat_kernel, dim3(flat_blocks(CG, npairs, 2, 4096)), dim3(256), (size_t)2 * d->C * sizeof(float),
+                           (hipStream_t)stream, *d, CG, (uint32_t)npairs);
+        DS_LAUNCH_CHECK("maxpool3s2_fwd");
+        return 0;
+    }
     ROW_DISPATCH(maxpool_fwd_kernel, d->C, Mo, *d, (hipStream_t)stream);
     DS_LAUNCH_CHECK("maxpool3s2_fwd");
     return 0;
@@ -692,6 +852,14 @@ extern "C" int dsaspp_maxpool3s2_bwd(const dsaspp_maxpool_desc* d, dsaspp_stream
     DS_REQUIRE(d->x && d->dy && d->dr && d->argmax && d->scale && d->shift && d->mean && d->rstd, "maxpool3s2_bwd: null tensor");
     const int64_t Mi = (int64_t)d->n_img * d->H * d->W;
     if (d->dtype == 1) return dsaspp_f32_maxpool_bwd(*d, (hipStream_t)stream);
+    if (!d->dr_f32 && Mi * (d->C / 8) < (1ll << 31)) {
+        const int CG = d->C / 8;
+        const int64_t npairs = Mi * CG;
+        hipLaunchKernelGGL(maxpool_bwd_flat_kernel, dim3(flat_blocks(CG, npairs, 4, 4096)), dim3(256), (size_t)2 * d->C * sizeof(float),
+                           (hipStream_t)stream, *d, CG, (uint32_t)npairs);
+        DS_LAUNCH_CHECK("maxpool3s2_bwd");
+        return 0;
+    }
     ROW_DISPATCH(maxpool_bwd_kernel, d->C, Mi, *d, (hipStream_t)stream);
     DS_LAUNCH_CHECK("maxpool3s2_bwd");
     return 0;

@@ -34,3 +34,16 @@ dr = torch.randn(M8 * C, device=dev).to(bf); y = torch.randn(M8 * C, device=dev)
 coef = torch.randn(3 * C, device=dev)
 timeit('bn_bwd_apply 192 @1/8', 'bn_bwd_apply', dict(M=M8, C=C, dr=Ref(dr), lddr=C, dr_f32=0, y=Ref(y), ldy=C, coefA=Ref(coef, 0), coefB=Ref(coef, C),
        coefC=Ref(coef, 2 * C), dy=Ref(dy), lddy=C, colsum=None, dtype=0), 3 * M8 * C * 2)
+
+# stem: BN + ReLU + 3x3/2 max-pool of conv0's output (96 channels at 1/2 resolution) and its backward
+H0, W0, C0 = 512, 1024, 96
+M0, Mp = n * H0 * W0, n * (H0 // 2) * (W0 // 2)
+x0 = torch.randn(M0 * C0, device=dev).to(bf); yp = torch.zeros(Mp * C0, device=dev).to(bf)
+am = torch.zeros(Mp * C0, device=dev, dtype=torch.uint8); acc = torch.zeros(16 * 2 * C0, device=dev)
+sc0, sh0, mu0, rs0 = vec(C0), vec(C0, -0.5), vec(C0, -0.5), vec(C0)
+mp = dict(n_img=n, H=H0, W=W0, C=C0, x=Ref(x0), ldx=C0, scale=Ref(sc0), shift=Ref(sh0), y=Ref(yp), ldy=C0, argmax=Ref(am), stat_acc=Ref(acc),
+          dy=None, lddy=0, dr=None, lddr=0, dr_f32=0, mean=None, rstd=None, s_acc=None, dtype=0)
+timeit('maxpool_fwd 96 @1/2', 'maxpool_fwd', mp, M0 * C0 * 2 + Mp * C0 * 3)
+dyp = torch.randn(Mp * C0, device=dev).to(bf); dr0 = torch.zeros(M0 * C0, device=dev).to(bf)
+mb = dict(mp); mb.update(y=None, ldy=0, stat_acc=None, dy=Ref(dyp), lddy=C0, dr=Ref(dr0), lddr=C0, mean=Ref(mu0), rstd=Ref(rs0), s_acc=Ref(acc))
+timeit('maxpool_bwd 96 @1/2', 'maxpool_bwd', mb, 2 * M0 * C0 * 2 + Mp * C0 * 3)
