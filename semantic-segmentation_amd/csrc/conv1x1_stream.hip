@@ -89,7 +89,11 @@ __global__ __launch_bounds__(NT) void conv1x1_stream_kernel(const dsaspp_conv_de
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
         const int row = (i * NWAVE + wave) * 8 + (lane >> 3);
-        int q = q_base + row;
+        // LDS row (tile 2 P + h, row 4 gq + e) holds output channel 32 P + 8 gq + 4 h + e: a lane of the accumulator layout then
+        // owns eight consecutive channels in two tiles, and the epilogue stores 16-byte pieces (64 consecutive bytes per pixel
+        // and instruction instead of 32)
+        const int tile = row >> 4, rw = row & 15;
+        int q = q_base + (tile >> 1) * 32 + (rw >> 2) * 8 + (tile & 1) * 4 + (rw & 3);
         q = q < cout ? q : cout - 1;               // rows past cout: any finite data, their results are never stored
         w_ptr[i] = wg + (int64_t)q * cin;
         wd_chunk[i] = ((lane & 7) ^ swz8(row)) * 8;   // the XOR swizzle lives in the source address
@@ -228,31 +232,39 @@ __global__ __launch_bounds__(NT) void conv1x1_stream_kernel(const dsaspp_conv_de
                  :
                  : "memory");
 
-    // ---- epilogue: lane holds output channels q = j*16 + g*4 .. +3 of pixel rows i*16 + fr
+    // ---- epilogue: lane holds output channels q_base + 32 P + 8 g .. + 7 (tiles 2 P and 2 P + 1) of pixel rows i*16 + fr
     u16* yg = reinterpret_cast<u16*>(d.y);
     const bool want_stats = d.stat_acc != nullptr;
+    static_assert(NJ % 2 == 0, "channel tiles are paired");
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int q = q_base + j * 16 + g * 4;
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int pr = 0; pr < NJ / 2; ++pr) {
+        const int qo = pr * 32 + g * 8, q = q_base + qo;
+        float s1[8], s2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = p0 + i * 16 + fr;
-            const uint32_t lo = pack_bf2(acc[i][j][0], acc[i][j][1]), hi = pack_bf2(acc[i][j][2], acc[i][j][3]);
-            if (rok[i] && q < cout) *reinterpret_cast<uint2*>(yg + (int64_t)m * d.ldy + q) = make_uint2(lo, hi);
-            if (want_stats) {      // statistics of the values as stored (rows past M contribute exact zeros)
-                const float v[4] = {bf_lo(lo), bf_hi(lo), bf_lo(hi), bf_hi(hi)};
+            uint32_t o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+            for (int h = 0; h < 4; ++h) o[h] = pack_bf2(acc[i][2 * pr + (h >> 1)][2 * (h & 1)], acc[i][2 * pr + (h >> 1)][2 * (h & 1) + 1]);
+            if (rok[i] && q < cout) *reinterpret_cast<uint4*>(yg + (int64_t)m * d.ldy + q) = make_uint4(o[0], o[1], o[2], o[3]);
+            if (want_stats) {      // statistics of the values as stored (rows past M contribute exact zeros)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const float v0 = bf_lo(o[h]), v1 = bf_hi(o[h]);
+                    s1[2 * h] += v0; s1[2 * h + 1] += v1;
+                    s2[2 * h] += v0 * v0; s2[2 * h + 1] += v1 * v1;
+                }
             }
         }
         if (want_stats) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 8; ++e) {
                 const float t1 = row16_sum(s1[e]), t2 = row16_sum(s2[e]);
                 if (fr == 0) {
-                    atomicAdd(sums + j * 16 + g * 4 + e, t1);
-                    atomicAdd(sums + BQ + j * 16 + g * 4 + e, t2);
+                    atomicAdd(sums + qo + e, t1);
+                    atomicAdd(sums + BQ + qo + e, t2);
                 }
             }
         }
@@ -291,7 +303,7 @@ int dsaspp_conv1x1_stream_launch(const dsaspp_conv_desc& d, hipStream_t s) {
     if (!form) return -1;
     const int64_t M = (int64_t)d.n_img * d.H * d.W;
     if (d.cout > 192 || d.cout < 96 || d.cout % 8 || d.cin % 8 || d.cin < 64 || M >= (1ll << 31)) return -1;
-    if (d.ldx % 8 || d.ldy % 4 || ((uintptr_t)d.x & 15) || ((uintptr_t)d.y & 7) || ((uintptr_t)d.w & 15)) return -1;
+    if (d.ldx % 8 || d.ldy % 8 || ((uintptr_t)d.x & 15) || ((uintptr_t)d.y & 15) || ((uintptr_t)d.w & 15)) return -1;    // 16-byte loads and stores
     const size_t lds192 = (size_t)NSLOT * 192 * 128 + (size_t)(2 * d.cin + 2 * 192) * sizeof(float);
     if (lds192 > 150 * 1024) return -1;
     if (d.cout <= 128) return launch_stream<128>(d, s);
