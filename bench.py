@@ -181,12 +181,32 @@ def main():
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
                          % (args.gpus, world, args.gpus))
+    # (rehearsal of the multi-rank control flow on a one-GPU box: DSASPP_BENCH_REHEARSAL=1 puts every rank on device 0 and
+    # exchanges through gloo with the device drained before each collective; it checks the rendezvous, the broadcast of
+    # the model, the bucket bookkeeping and the reduction of the timings, and its numbers mean nothing)
+    rehearsal = os.environ.get('DSASPP_BENCH_REHEARSAL') == '1'
+    if rehearsal:
+        local_rank = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get('DSASPP_BENCH_WATCHDOG', '120')), exit=True)   # a hang names its line
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1 or args.force_reducer:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+            # torch's gloo backend on this ROCm image never completes an asynchronous collective of a GPU tensor issued
+            # behind queued kernels (tools/gloo_cuda_probe.py shows it with torch's own matmuls): drain the device first
+            _all_reduce = dist.all_reduce
+
+            def _drained_all_reduce(t, *a, **k):
+                if t.is_cuda:
+                    torch.cuda.synchronize()
+                return _all_reduce(t, *a, **k)
+            dist.all_reduce = _drained_all_reduce
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     import importlib
     import denseASPP
@@ -209,8 +229,12 @@ def main():
     model.refresh_weights()
 
     def step():
+        t_s = time.time()
         loss = model.train_step(x, labels, generator=gen, refresh=False, reducer=reducer)
         opt.step(grad_scale=1.0 / world)
+        if rehearsal:
+            torch.cuda.synchronize()
+            print('[rehearsal] rank %d step %.2f s' % (rank, time.time() - t_s), file=sys.stderr, flush=True)
         return loss
 
     def sync():
@@ -275,6 +299,16 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     loss_val = float(loss)
+    if rehearsal and world > 1:
+        # every rank saw other data: the replicas stay bit-identical only if every gradient went through the exchange
+        chk = torch.stack([model._flat.double().sum(), model._flat.double().abs().sum()]).cpu()
+        seen = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(seen, chk)
+        same = all(torch.equal(seen[0], c) for c in seen)
+        print('[rehearsal] rank %d: replicas identical after %d steps: %s' % (rank, args.warmup + args.steps + 1, same),
+              file=sys.stderr, flush=True)
+        if not same:
+            raise SystemExit('rehearsal: the replicas diverged')
 
     roofline = None
     if timing:
