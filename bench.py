@@ -206,6 +206,14 @@ def main():
                 return _all_reduce(t, *a, **k)
             dist.all_reduce = _drained_all_reduce
         else:
+            # RCCL runs one workgroup per channel; no more channels than the compute units the persistent kernels leave free
+            # while gradient buckets are in flight, or the collective's workgroups and the one-block-per-CU kernels queue
+            # behind each other (an explicit NCCL_MAX_NCHANNELS in the environment wins)
+            import denseASPP  # noqa: F401  (registers the package under its importable name)
+            from semantic_segmentation_amd.distributed import DEFAULT_COMM_CUS
+            cus = args.comm_cus if args.comm_cus is not None else int(os.environ.get('DSASPP_COMM_CUS', DEFAULT_COMM_CUS))
+            if cus > 0:
+                os.environ.setdefault('NCCL_MAX_NCHANNELS', str(cus))
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     import importlib
