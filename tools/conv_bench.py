@@ -74,6 +74,10 @@ for dl in (1, 2, 4):          # 3x3 data gradient with the slab read-out as its 
     cases['dgrad3x3_fused_d%d' % dl] = conv(n_img=n, H=H, W=W, cin=48, cout=192, taps=9, dil=dl, x=Ref(g16, c_lo), ldx=LD, w=Ref(w2t), y=Ref(dr16), ldy=192, epi_relu=1, ref=Ref(y1), ldref=192,
         e_scale=Ref(sc2), e_shift=Ref(sh2), e_mean=Ref(mean), e_rstd=Ref(rstd), s_acc=Ref(acc), gx_corr1=Ref(corr, c_lo), gx_corr2=Ref(corr, LD + c_lo), gx_xs=Ref(slab, c_lo), gx_ldxs=LD,
         gx_mean=Ref(mean, c_lo), gx_rstd=Ref(rstd, c_lo), gx_dz=Ref(dz48), gx_lddz=48)
+w3a = (torch.randn(128*9*512, device=dev)*0.02).to(bf); sc512, sh512 = vec(512), vec(512, -0.5); b128 = vec(128, -0.5)
+for dl in (3, 12, 24):        # ASPP 3x3 forward: 512 -> 128, written into the ASPP slab
+    cases['aspp_fwd3x3_d%d' % dl] = conv(n_img=n, H=H, W=W, cin=512, cout=128, taps=9, dil=dl, x=Ref(y512), ldx=512, w=Ref(w3a), in_scale=Ref(sc512), in_shift=Ref(sh512),
+                                         in_relu=1, bias=Ref(b128), y=Ref(slab, 1024), ldy=LD, stat_acc=Ref(acc))
 dwg = [torch.zeros(192*CIN, device=dev) for _ in range(4)]
 def wgroup(nsrc, ks=0):
     f = dict(n_img=n, H=H, W=W, cin=CIN, cout=192, taps=1, dil=1, x=Ref(slab), ldx=LD, in_scale=Ref(sc1), in_shift=Ref(sh1), in_relu=1, in_mask=None,
